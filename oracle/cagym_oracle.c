@@ -1,0 +1,702 @@
+/* cagym_oracle.c -- CPU restatement (parity oracle) of the reference env.step() hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY (see cagym_oracle.h).  Plain C, scalar, fp64 state exactly as
+ * the NumPy reference keeps it (agent.py:21-25); actions pass through fp32
+ * (collision_avoidance_env.py:289).  Compile with -ffp-contract=off so no FMA is formed.
+ *
+ * Citations: `env.py` = gym_collision_avoidance/envs/collision_avoidance_env.py, other
+ * paths relative to gym_collision_avoidance/envs/ of the reference.
+ */
+#include "cagym_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <float.h>
+
+#define MAPD 300 /* int(30/0.1), Map.py:18 */
+#define NBEAM 16 /* Config.LASERSCAN_LENGTH, config.py:57 */
+#define NSAMP 16 /* len(arange(0, 6, 2*pi/16)), sensors/LaserScanSensor.py:20 */
+
+static const double PI = 3.141592653589793; /* np.pi */
+
+struct cao_env {
+    cao_config cfg;
+    int N, M, K, Kobs; /* K = M-1 OAS rows */
+    /* scenario */
+    double *sc_agents6, *sc_heading0, *sc_coop, *sc_obst;
+    int32_t *sc_policy, *sc_dyn, *sc_nagents, *sc_nobst;
+    uint8_t* sc_has_heading;
+    /* state, all [N*M*w] */
+    double* f[CAO_F_COUNT];
+    uint8_t* u[CAO_U_COUNT];
+    int32_t* i32[CAO_I_COUNT];
+    double *goal, *radius, *pref_speed, *ref_orth, *ang_speed, *cur_speed, *cur_turn, *coop;
+    int32_t *policy, *dyn, *nagents, *nobst;
+};
+
+static const int F_WIDTH[CAO_F_COUNT] = {2, 2, 1, 1, 1, 1, 1, 1, 2, 2, 2, 1, 1, 4, 1, 0 /*oas*/, NBEAM, 2};
+
+/* util.py:27-32 */
+static double wrap(double a) {
+    while (a >= PI) a -= 2 * PI;
+    while (a < -PI) a += 2 * PI;
+    return a;
+}
+static double clipd(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
+/* np.dot of 2-vectors and np.linalg.norm (= sqrt(x.dot(x))).  As executed for the golden
+ * vectors (NumPy 2.2.6 + OpenBLAS 0.3.29 Haswell ddot) the 2-element dot product is
+ * fma(a1, b1, a0*b0): verified bit-for-bit on 20 000 random vectors ("BLAS
+ * rounding").  Call sites that use math.sqrt(x**2 + y**2) instead stay plain. */
+static double dot2(double a0, double a1, double b0, double b1) { return fma(a1, b1, a0 * b0); }
+static double norm2(double x, double y) { return sqrt(dot2(x, y, x, y)); }
+
+cao_env* cao_create(const cao_config* cfg) {
+    cao_env* e = (cao_env*)calloc(1, sizeof(cao_env));
+    e->cfg = *cfg;
+    int N = e->N = cfg->n_worlds, M = e->M = cfg->max_agents;
+    e->K = M - 1;
+    e->Kobs = cfg->max_obstacles;
+    size_t NM = (size_t)N * M;
+    for (int k = 0; k < CAO_F_COUNT; k++) {
+        size_t w = k == CAO_F_OAS ? (size_t)e->K * 10 : (size_t)F_WIDTH[k];
+        e->f[k] = (double*)calloc(NM * w + 1, sizeof(double));
+    }
+    for (int k = 0; k < CAO_U_COUNT; k++) {
+        size_t n = k == CAO_U_GAME_OVER ? (size_t)N : (k == CAO_U_MAP ? (e->Kobs ? (size_t)N * MAPD * MAPD : 1) : NM);
+        e->u[k] = (uint8_t*)calloc(n, 1);
+    }
+    for (int k = 0; k < CAO_I_COUNT; k++) e->i32[k] = (int32_t*)calloc(NM, sizeof(int32_t));
+    e->goal = (double*)calloc(NM * 2, sizeof(double));
+    e->ref_orth = (double*)calloc(NM * 2, sizeof(double));
+    e->radius = (double*)calloc(NM, sizeof(double));
+    e->pref_speed = (double*)calloc(NM, sizeof(double));
+    e->ang_speed = (double*)calloc(NM, sizeof(double));
+    e->cur_speed = (double*)calloc(NM, sizeof(double));
+    e->cur_turn = (double*)calloc(NM, sizeof(double));
+    e->coop = (double*)calloc(NM, sizeof(double));
+    e->policy = (int32_t*)calloc(NM, sizeof(int32_t));
+    e->dyn = (int32_t*)calloc(NM, sizeof(int32_t));
+    e->nagents = (int32_t*)calloc(N, sizeof(int32_t));
+    e->nobst = (int32_t*)calloc(N, sizeof(int32_t));
+    e->sc_agents6 = (double*)calloc(NM * 6, sizeof(double));
+    e->sc_heading0 = (double*)calloc(NM, sizeof(double));
+    e->sc_coop = (double*)calloc(NM, sizeof(double));
+    e->sc_obst = (double*)calloc((size_t)N * (e->Kobs ? e->Kobs : 1) * 4, sizeof(double));
+    e->sc_policy = (int32_t*)calloc(NM, sizeof(int32_t));
+    e->sc_dyn = (int32_t*)calloc(NM, sizeof(int32_t));
+    e->sc_nagents = (int32_t*)calloc(N, sizeof(int32_t));
+    e->sc_nobst = (int32_t*)calloc(N, sizeof(int32_t));
+    e->sc_has_heading = (uint8_t*)calloc(1, 1);
+    return e;
+}
+
+void cao_destroy(cao_env* e) {
+    if (!e) return;
+    for (int k = 0; k < CAO_F_COUNT; k++) free(e->f[k]);
+    for (int k = 0; k < CAO_U_COUNT; k++) free(e->u[k]);
+    for (int k = 0; k < CAO_I_COUNT; k++) free(e->i32[k]);
+    free(e->goal); free(e->ref_orth); free(e->radius); free(e->pref_speed); free(e->ang_speed);
+    free(e->cur_speed); free(e->cur_turn); free(e->coop); free(e->policy); free(e->dyn);
+    free(e->nagents); free(e->nobst); free(e->sc_agents6); free(e->sc_heading0); free(e->sc_coop);
+    free(e->sc_obst); free(e->sc_policy); free(e->sc_dyn); free(e->sc_nagents); free(e->sc_nobst);
+    free(e->sc_has_heading);
+    free(e);
+}
+
+double* cao_f64(cao_env* e, int field) { return e->f[field]; }
+uint8_t* cao_u8(cao_env* e, int field) { return e->u[field]; }
+int32_t* cao_i32(cao_env* e, int field) { return e->i32[field]; }
+
+void cao_set_scenario(cao_env* e, const double* agents6, const double* heading0, const int32_t* policy_id,
+                      const int32_t* dynamics_id, const int32_t* n_agents, const double* coop,
+                      const double* obstacles, const int32_t* n_obst) {
+    size_t NM = (size_t)e->N * e->M;
+    memcpy(e->sc_agents6, agents6, NM * 6 * sizeof(double));
+    e->sc_has_heading[0] = heading0 != NULL;
+    if (heading0) memcpy(e->sc_heading0, heading0, NM * sizeof(double));
+    memcpy(e->sc_policy, policy_id, NM * sizeof(int32_t));
+    memcpy(e->sc_dyn, dynamics_id, NM * sizeof(int32_t));
+    for (int w = 0; w < e->N; w++) e->sc_nagents[w] = n_agents ? n_agents[w] : e->M;
+    for (size_t k = 0; k < NM; k++) e->sc_coop[k] = coop ? coop[k] : 1.0; /* agent.py:10 */
+    for (int w = 0; w < e->N; w++) e->sc_nobst[w] = (n_obst && e->Kobs) ? n_obst[w] : 0;
+    if (obstacles && e->Kobs) memcpy(e->sc_obst, obstacles, (size_t)e->N * e->Kobs * 4 * sizeof(double));
+}
+
+/* Map.world_coordinates_to_map_indices (Map.py:40-47) */
+static int world_to_cell(double x, double y, int* gx, int* gy) {
+    double cell = 0.1, ox = (30 / 2.) / cell, oy = (30 / 2.) / cell; /* Map.py:19 */
+    *gx = (int)floor(ox - y / cell);
+    *gy = (int)floor(oy + x / cell);
+    return *gx >= 0 && *gy >= 0 && *gx < MAPD && *gy < MAPD;
+}
+
+/* Map.get_occupancy_grid (Map.py:107-123); obstacle corners [(xu,yu),(xl,yu),(xl,yl),(xu,yl)]
+ * (test_cases.py:2496): filled inclusive from cell(corner[1]) to cell(corner[3]).  Python's
+ * negative-index wrap is reproduced; indices >= 300 (IndexError in the reference) are skipped. */
+void cao_rasterize(const double* obst, int n_obst, uint8_t* map) {
+    memset(map, 0, MAPD * MAPD);
+    for (int o = 0; o < n_obst; o++) {
+        double xl = obst[o * 4 + 0], yl = obst[o * 4 + 1], xu = obst[o * 4 + 2], yu = obst[o * 4 + 3];
+        int s0, s1, e0, e1;
+        world_to_cell(xl, yu, &s0, &s1);
+        world_to_cell(xu, yl, &e0, &e1);
+        for (int ii = s0; ii <= e0; ii++)
+            for (int jj = s1; jj <= e1; jj++) {
+                int a = ii < 0 ? ii + MAPD : ii, b = jj < 0 ? jj + MAPD : jj;
+                if (a < 0 || b < 0 || a >= MAPD || b >= MAPD) continue;
+                map[a * MAPD + b] = 1;
+            }
+    }
+}
+
+/* Dynamics.update_ego_frame (dynamics/Dynamics.py:14-28) + Agent.get_ref (agent.py:250-269) */
+static void update_ego_frame(cao_env* e, size_t a) {
+    double* pos = e->f[CAO_F_POS] + 2 * a;
+    double* goal = e->goal + 2 * a;
+    double gx = goal[0] - pos[0], gy = goal[1] - pos[1];
+    e->f[CAO_F_PAST_DIST_TO_GOAL][a] = e->f[CAO_F_DIST_TO_GOAL][a];
+    double dist = sqrt(gx * gx + gy * gy);
+    e->f[CAO_F_DIST_TO_GOAL][a] = dist;
+    if (e->f[CAO_F_T][a] == 0) e->f[CAO_F_PAST_DIST_TO_GOAL][a] = dist;
+    double px = gx, py = gy;
+    if (dist > 1e-8) { px = gx / dist; py = gy / dist; }
+    e->f[CAO_F_REF_PRLL][2 * a] = px;
+    e->f[CAO_F_REF_PRLL][2 * a + 1] = py;
+    e->ref_orth[2 * a] = -py;
+    e->ref_orth[2 * a + 1] = px;
+    double ang = atan2(py, px);
+    double he = wrap(e->f[CAO_F_HEADING][a] - ang);
+    e->f[CAO_F_HEADING_EGO][a] = he;
+    double* vel = e->f[CAO_F_VEL] + 2 * a;
+    double sp = sqrt(vel[0] * vel[0] + vel[1] * vel[1]);
+    e->f[CAO_F_VEL_EGO][2 * a] = sp * cos(he);
+    e->f[CAO_F_VEL_EGO][2 * a + 1] = sp * sin(he);
+    e->f[CAO_F_REL_GOAL][2 * a] = goal[0] - pos[0];
+    e->f[CAO_F_REL_GOAL][2 * a + 1] = goal[1] - pos[1];
+}
+
+/* Agent.__init__ (agent.py:9-109) */
+static void init_agent(cao_env* e, int w, int i) {
+    size_t a = (size_t)w * e->M + i;
+    const double* s = e->sc_agents6 + a * 6;
+    double* pos = e->f[CAO_F_POS] + 2 * a;
+    pos[0] = s[0]; pos[1] = s[1];
+    e->goal[2 * a] = s[2]; e->goal[2 * a + 1] = s[3];
+    e->pref_speed[a] = s[4];
+    e->radius[a] = s[5];
+    e->f[CAO_F_VEL][2 * a] = e->f[CAO_F_VEL][2 * a + 1] = 0.0;
+    e->f[CAO_F_SPEED][a] = 0.0;
+    e->ang_speed[a] = 0.0;
+    if (e->sc_has_heading[0]) e->f[CAO_F_HEADING][a] = e->sc_heading0[a];
+    else e->f[CAO_F_HEADING][a] = atan2(s[3] - s[1], s[2] - s[0]); /* agent.py:29-31 */
+    e->f[CAO_F_DELTA_HEADING][a] = 0.0;
+    e->f[CAO_F_HEADING_EGO][a] = 0.0;
+    e->f[CAO_F_VEL_EGO][2 * a] = e->f[CAO_F_VEL_EGO][2 * a + 1] = 0.0;
+    memset(e->f[CAO_F_PAST_ACTIONS] + 4 * a, 0, 4 * sizeof(double));
+    e->f[CAO_F_ACTION][2 * a] = e->f[CAO_F_ACTION][2 * a + 1] = 0.0;
+    e->f[CAO_F_DIST_TO_GOAL][a] = 0.0;
+    /* agent.py:59-63, config.py:60-61 */
+    double straight = (norm2(pos[0] - s[2], pos[1] - s[3]) - 0.75) / s[4];
+    e->f[CAO_F_TIME_REMAINING][a] = 3.0 * straight;
+    e->f[CAO_F_T][a] = 0.0;
+    e->i32[CAO_I_STEP_NUM][a] = 0;
+    e->u[CAO_U_IS_AT_GOAL][a] = e->u[CAO_U_WAS_AT_GOAL][a] = 0;
+    e->u[CAO_U_IN_COLLISION][a] = e->u[CAO_U_WAS_IN_COLLISION][a] = 0;
+    e->u[CAO_U_RAN_OUT_OF_TIME][a] = e->u[CAO_U_IS_DONE][a] = 0;
+    e->cur_speed[a] = e->cur_turn[a] = 0.0; /* UnicycleDynamicsMaxAcc.py:13-16 */
+    e->policy[a] = e->sc_policy[a];
+    e->dyn[a] = e->sc_dyn[a];
+    e->coop[a] = e->sc_coop[a];
+    e->f[CAO_F_REWARD][a] = 0.0;
+    update_ego_frame(e, a); /* agent.py:92 */
+}
+
+/* OtherAgentsStatesSensor.sense (sensors/OtherAgentsStatesSensor.py:11-77) */
+static void sense_oas(cao_env* e, int w, int i) {
+    int M = e->M, K = e->K, n = e->nagents[w];
+    size_t base = (size_t)w * M, a = base + i;
+    double* out = e->f[CAO_F_OAS] + a * K * 10;
+    memset(out, 0, (size_t)K * 10 * sizeof(double));
+    int idx[64];
+    double key[64];
+    int cnt = 0;
+    const double* P = e->f[CAO_F_POS];
+    for (int j = 0; j < n; j++) {
+        if (j == i) continue;
+        double dx = P[2 * (base + j)] - P[2 * a], dy = P[2 * (base + j) + 1] - P[2 * a + 1];
+        double dc = norm2(dx, dy);
+        double d2 = dc - e->radius[a] - e->radius[base + j];
+        /* SENSING_HORIZON = inf (config.py:63): never skipped */
+        idx[cnt] = j; key[cnt] = d2; cnt++;
+    }
+    /* stable ascending insertion sort (Python sorted), then reverse, keep last K (:28-34) */
+    for (int p = 1; p < cnt; p++) {
+        int ji = idx[p]; double kk = key[p]; int q = p - 1;
+        while (q >= 0 && key[q] > kk) { idx[q + 1] = idx[q]; key[q + 1] = key[q]; q--; }
+        idx[q + 1] = ji; key[q + 1] = kk;
+    }
+    int order[64];
+    for (int p = 0; p < cnt; p++) order[p] = idx[cnt - 1 - p];
+    int start = cnt > K ? cnt - K : 0;
+    int row = 0;
+    const double* prll = e->f[CAO_F_REF_PRLL] + 2 * a;
+    const double* orth = e->ref_orth + 2 * a;
+    for (int p = start; p < cnt; p++, row++) {
+        size_t b = base + order[p];
+        double dx = P[2 * b] - P[2 * a], dy = P[2 * b + 1] - P[2 * a + 1];
+        const double* v = e->f[CAO_F_VEL] + 2 * b;
+        double* r = out + row * 10;
+        r[0] = dx; r[1] = dy;
+        r[2] = dot2(dx, dy, prll[0], prll[1]);
+        r[3] = dot2(dx, dy, orth[0], orth[1]);
+        r[4] = dot2(v[0], v[1], prll[0], prll[1]);
+        r[5] = dot2(v[0], v[1], orth[0], orth[1]);
+        r[6] = e->radius[b];
+        r[7] = e->radius[a] + e->radius[b];
+        r[8] = norm2(dx, dy) - e->radius[a] - e->radius[b];
+        r[9] = e->policy[b] == CAO_POL_STATIC ? 1.0 : 2.0;
+    }
+    e->i32[CAO_I_NUM_OBSERVED][a] = row;
+}
+
+/* LaserScanSensor.sense (sensors/LaserScanSensor.py:9-22,27-58) with Map.py:49-79 */
+static void sense_laser(cao_env* e, int w, int i) {
+    size_t a = (size_t)w * e->M + i;
+    double* out = e->f[CAO_F_LASERSCAN] + a * NBEAM;
+    const uint8_t* map = e->nobst[w] > 0 ? e->u[CAO_U_MAP] + (size_t)w * MAPD * MAPD : NULL;
+    double px = e->f[CAO_F_POS][2 * a], py = e->f[CAO_F_POS][2 * a + 1], h = e->f[CAO_F_HEADING][a];
+    int egx, egy;
+    int ego_in = world_to_cell(px, py, &egx, &egy); /* Map.get_agent_mask, Map.py:73-79 */
+    double rr = e->radius[a] / 0.1;
+    double r2 = rr * rr;
+    double astep = (PI - (-PI)) / 15.0;     /* np.linspace(-pi, pi, 16) */
+    double rstep = 2 * PI / 16;             /* range_resolution, LaserScanSensor.py:13 */
+    for (int b = 0; b < NBEAM; b++) {
+        double ang0 = b == NBEAM - 1 ? PI : (double)b * astep + (-PI);
+        double ang = ang0 + h;
+        double ca = cos(ang), sa = sin(ang);
+        int count = 0, last = -1;
+        for (int k = 0; k < NSAMP; k++) {
+            double rg = 0.0 + (double)k * rstep;
+            double x = px + rg * ca, y = py + rg * sa;
+            int gx, gy;
+            int in_map = world_to_cell(x, y, &gx, &gy);
+            int hit = 0;
+            if (in_map && map && map[gx * MAPD + gy]) {
+                int masked = 0;
+                if (ego_in) {
+                    double dx = (double)(gy - egy), dy = (double)(gx - egx);
+                    masked = dx * dx + dy * dy < r2; /* Map.get_agent_map_indices, Map.py:67-71 */
+                }
+                hit = !masked;
+            }
+            count += hit;
+            if (count == 1) last = k; /* ranges[first_hits[0]] = ...: last k with cumsum == 1 wins (:43-47) */
+        }
+        double range = last >= 0 ? 0.0 + (double)last * rstep : 6.0;
+        out[b] = 1 - range / 6;
+    }
+}
+
+static void sense_world(cao_env* e, int w) {
+    for (int i = 0; i < e->nagents[w]; i++) {
+        sense_oas(e, w, i);
+        if (e->cfg.laserscan) sense_laser(e, w, i);
+    }
+}
+
+void cao_reset(cao_env* e, const uint8_t* world_mask) {
+    for (int w = 0; w < e->N; w++) {
+        if (world_mask && !world_mask[w]) continue;
+        e->nagents[w] = e->sc_nagents[w];
+        e->nobst[w] = e->sc_nobst[w];
+        if (e->Kobs && e->nobst[w] > 0)
+            cao_rasterize(e->sc_obst + (size_t)w * e->Kobs * 4, e->nobst[w], e->u[CAO_U_MAP] + (size_t)w * MAPD * MAPD);
+        for (int i = 0; i < e->M; i++) init_agent(e, w, i);
+        e->u[CAO_U_GAME_OVER][w] = 0;
+        sense_world(e, w); /* env.py:266 */
+    }
+}
+
+/* CARRLPolicy table (policies/CARRLPolicy.py:5-15): speed 1, dh = linspace(-pi/6, pi/6, 11) */
+static double carrl_heading(int k) {
+    double lo = -(PI / 6), hi = PI / 6;
+    double step = (hi - lo) / 10.0;
+    if (k == 10) return hi;
+    return (double)k * step + lo;
+}
+
+/* ---------------- ORCA (RVO2 v2.0 Agent::computeNewVelocity) ---------------- */
+typedef struct { float px, py, dx, dy; } orca_line;
+#define RVO_EPS 0.00001f
+static float detf(float ax, float ay, float bx, float by) { return ax * by - ay * bx; }
+
+static int lp1(const orca_line* L, int no, float radius, float ox, float oy, int dir_opt, float* rx, float* ry) {
+    float dot = L[no].px * L[no].dx + L[no].py * L[no].dy;
+    float disc = dot * dot + radius * radius - (L[no].px * L[no].px + L[no].py * L[no].py);
+    if (disc < 0.0f) return 0;
+    float sq = sqrtf(disc);
+    float tl = -dot - sq, tr = -dot + sq;
+    for (int i = 0; i < no; i++) {
+        float den = detf(L[no].dx, L[no].dy, L[i].dx, L[i].dy);
+        float num = detf(L[i].dx, L[i].dy, L[no].px - L[i].px, L[no].py - L[i].py);
+        if (fabsf(den) <= RVO_EPS) {
+            if (num < 0.0f) return 0;
+            continue;
+        }
+        float t = num / den;
+        if (den >= 0.0f) tr = tr < t ? tr : t;
+        else tl = tl > t ? tl : t;
+        if (tl > tr) return 0;
+    }
+    float t;
+    if (dir_opt) {
+        t = (ox * L[no].dx + oy * L[no].dy > 0.0f) ? tr : tl;
+    } else {
+        t = L[no].dx * (ox - L[no].px) + L[no].dy * (oy - L[no].py);
+        if (t < tl) t = tl;
+        else if (t > tr) t = tr;
+    }
+    *rx = L[no].px + t * L[no].dx;
+    *ry = L[no].py + t * L[no].dy;
+    return 1;
+}
+
+static int lp2(const orca_line* L, int n, float radius, float ox, float oy, int dir_opt, float* rx, float* ry) {
+    if (dir_opt) { *rx = ox * radius; *ry = oy * radius; }
+    else if (ox * ox + oy * oy > radius * radius) {
+        float inv = 1.0f / sqrtf(ox * ox + oy * oy); /* normalize(): Vector2 / abs */
+        *rx = ox * inv * radius; *ry = oy * inv * radius;
+    } else { *rx = ox; *ry = oy; }
+    for (int i = 0; i < n; i++) {
+        if (detf(L[i].dx, L[i].dy, L[i].px - *rx, L[i].py - *ry) > 0.0f) {
+            float tx = *rx, ty = *ry;
+            if (!lp1(L, i, radius, ox, oy, dir_opt, rx, ry)) { *rx = tx; *ry = ty; return i; }
+        }
+    }
+    return n;
+}
+
+static void lp3(const orca_line* L, int n, int begin, float radius, float* rx, float* ry) {
+    float distance = 0.0f;
+    orca_line P[64];
+    for (int i = begin; i < n; i++) {
+        if (detf(L[i].dx, L[i].dy, L[i].px - *rx, L[i].py - *ry) > distance) {
+            int np = 0;
+            for (int j = 0; j < i; j++) {
+                orca_line ln;
+                float d = detf(L[i].dx, L[i].dy, L[j].dx, L[j].dy);
+                if (fabsf(d) <= RVO_EPS) {
+                    if (L[i].dx * L[j].dx + L[i].dy * L[j].dy > 0.0f) continue;
+                    ln.px = 0.5f * (L[i].px + L[j].px);
+                    ln.py = 0.5f * (L[i].py + L[j].py);
+                } else {
+                    float s = detf(L[j].dx, L[j].dy, L[i].px - L[j].px, L[i].py - L[j].py) / d;
+                    ln.px = L[i].px + s * L[i].dx;
+                    ln.py = L[i].py + s * L[i].dy;
+                }
+                float ddx = L[j].dx - L[i].dx, ddy = L[j].dy - L[i].dy;
+                float inv = 1.0f / sqrtf(ddx * ddx + ddy * ddy);
+                ln.dx = ddx * inv; ln.dy = ddy * inv;
+                P[np++] = ln;
+            }
+            float tx = *rx, ty = *ry;
+            if (lp2(P, np, radius, -L[i].dy, L[i].dx, 1, rx, ry) < np) { *rx = tx; *ry = ty; }
+            distance = detf(L[i].dx, L[i].dy, L[i].px - *rx, L[i].py - *ry);
+        }
+    }
+}
+
+/* RVOPolicy.find_next_action (policies/RVOPolicy.py:53-117), ego LP only.
+ * Simulator parameters RVOPolicy.py:25-28: timeStep 0.1, neighborDist inf, maxNeighbors 10,
+ * timeHorizon 5.  Neighbours are visited in index order (the real library's k-d tree order
+ * is unpinned), nearest first, at most 10.  collab: line.point = v + collab*u (assumed
+ * semantics of the mit-acl fork's setAgentCollabCoeff; stock RVO2 uses 0.5). */
+void cao_orca_action(int M, int ego, const double* pos, const double* vel, const double* goal,
+                     const double* pref_speed, const double* radius, double heading, double collab,
+                     double dt, double* action_out) {
+    float p[64][2], v[64][2], r[64];
+    for (int a = 0; a < M; a++) {
+        p[a][0] = (float)pos[2 * a]; p[a][1] = (float)pos[2 * a + 1];
+        v[a][0] = (float)vel[2 * a]; v[a][1] = (float)vel[2 * a + 1];
+        r[a] = (float)((1 + 15e-2) * radius[a]);
+    }
+    double gx = goal[2 * ego] - pos[2 * ego], gy = goal[2 * ego + 1] - pos[2 * ego + 1];
+    double sc = pref_speed[ego] / norm2(gx, gy);
+    float pvx = (float)(sc * gx), pvy = (float)(sc * gy);
+    float max_speed = (float)pref_speed[ego];
+    float time_step = (float)dt, time_horizon = 5.0f;
+    /* neighbour list: insertion by distSq, strict <, max 10 (Agent::insertAgentNeighbor) */
+    int nb[10]; float nd[10]; int nn = 0;
+    float range_sq = INFINITY;
+    for (int a = 0; a < M; a++) {
+        if (a == ego) continue;
+        float dx = p[ego][0] - p[a][0], dy = p[ego][1] - p[a][1];
+        float dsq = dx * dx + dy * dy;
+        if (dsq < range_sq) {
+            if (nn < 10) nn++;
+            int i = nn - 1;
+            while (i != 0 && dsq < nd[i - 1]) { nb[i] = nb[i - 1]; nd[i] = nd[i - 1]; i--; }
+            nb[i] = a; nd[i] = dsq;
+            if (nn == 10) range_sq = nd[nn - 1];
+        }
+    }
+    orca_line L[10];
+    float inv_th = 1.0f / time_horizon;
+    float c = (float)collab;
+    for (int k = 0; k < nn; k++) {
+        int o = nb[k];
+        float rpx = p[o][0] - p[ego][0], rpy = p[o][1] - p[ego][1];
+        float rvx = v[ego][0] - v[o][0], rvy = v[ego][1] - v[o][1];
+        float dsq = rpx * rpx + rpy * rpy;
+        float cr = r[ego] + r[o], crsq = cr * cr;
+        float ux, uy;
+        orca_line ln;
+        if (dsq > crsq) {
+            float wx = rvx - inv_th * rpx, wy = rvy - inv_th * rpy;
+            float wlsq = wx * wx + wy * wy;
+            float dp1 = wx * rpx + wy * rpy;
+            if (dp1 < 0.0f && dp1 * dp1 > crsq * wlsq) {
+                float wl = sqrtf(wlsq);
+                float inv = 1.0f / wl;
+                float uwx = wx * inv, uwy = wy * inv;
+                ln.dx = uwy; ln.dy = -uwx;
+                float s = cr * inv_th - wl;
+                ux = s * uwx; uy = s * uwy;
+            } else {
+                float leg = sqrtf(dsq - crsq);
+                float inv = 1.0f / dsq;
+                if (detf(rpx, rpy, wx, wy) > 0.0f) {
+                    ln.dx = (rpx * leg - rpy * cr) * inv;
+                    ln.dy = (rpx * cr + rpy * leg) * inv;
+                } else {
+                    ln.dx = -((rpx * leg + rpy * cr) * inv);
+                    ln.dy = -((-rpx * cr + rpy * leg) * inv);
+                }
+                float dp2 = rvx * ln.dx + rvy * ln.dy;
+                ux = dp2 * ln.dx - rvx; uy = dp2 * ln.dy - rvy;
+            }
+        } else {
+            float inv_ts = 1.0f / time_step;
+            float wx = rvx - inv_ts * rpx, wy = rvy - inv_ts * rpy;
+            float wl = sqrtf(wx * wx + wy * wy);
+            float inv = 1.0f / wl;
+            float uwx = wx * inv, uwy = wy * inv;
+            ln.dx = uwy; ln.dy = -uwx;
+            float s = cr * inv_ts - wl;
+            ux = s * uwx; uy = s * uwy;
+        }
+        ln.px = v[ego][0] + c * ux;
+        ln.py = v[ego][1] + c * uy;
+        L[k] = ln;
+    }
+    float nvx, nvy;
+    int fail = lp2(L, nn, max_speed, pvx, pvy, 0, &nvx, &nvy);
+    if (fail < nn) lp3(L, nn, fail, max_speed, &nvx, &nvy);
+    /* Agent::update: position_ += velocity_ * timeStep_ (fp32) */
+    float npx = p[ego][0] + nvx * time_step, npy = p[ego][1] + nvy * time_step;
+    /* back in Python, fp64 (RVOPolicy.py:91-106) */
+    double dpx = (double)npx - pos[2 * ego], dpy = (double)npy - pos[2 * ego + 1];
+    double ang1 = atan2(dpy, dpx);
+    double nh = fmod(ang1, 2 * PI);
+    if (nh < 0) nh += 2 * PI; /* Python float modulo: result has the divisor's sign */
+    double dh = wrap(nh - heading);
+    double speed = 1 / dt * norm2(dpx, dpy);
+    if (fabs(dh) > PI / 6) {
+        dh = (dh > 0 ? 1.0 : (dh < 0 ? -1.0 : 0.0)) * (PI / 6);
+        speed = 0.;
+    }
+    action_out[0] = speed;
+    action_out[1] = dh;
+}
+
+/* _take_action policy dispatch (env.py:287-340) for one agent: returns the fp32-rounded action */
+static void select_action(cao_env* e, int w, int i, const double* ext, float* act) {
+    size_t base = (size_t)w * e->M, a = base + i;
+    double a0 = 0.0, a1 = 0.0;
+    act[0] = act[1] = 0.0f; /* env.py:289 */
+    if (e->u[CAO_U_IS_DONE][a]) return; /* env.py:299-300 */
+    switch (e->policy[a]) {
+        case CAO_POL_STATIC: a0 = 0.0; a1 = 0.0; break; /* StaticPolicy.py:9-12 */
+        case CAO_POL_NONCOOP: /* NonCooperativePolicy.py:10-13 */
+            a0 = e->pref_speed[a]; a1 = -e->f[CAO_F_HEADING_EGO][a]; break;
+        case CAO_POL_EXTERNAL: case CAO_POL_IGMCTS: case CAO_POL_GA3C:
+            a0 = ext ? ext[2 * a] : 0.0; a1 = ext ? ext[2 * a + 1] : 0.0; break;
+        case CAO_POL_LEARNING: /* LearningPolicy.py:11-16, max_heading_change = 4 (env.py:97,466-468) */
+            a1 = 4.0 * (2. * (ext ? ext[2 * a + 1] : 0.0) - 1.);
+            a0 = e->pref_speed[a] * (ext ? ext[2 * a] : 0.0);
+            break;
+        case CAO_POL_CARRL: {
+            int k = ext ? (int)ext[2 * a] : 0;
+            a0 = 1.0; a1 = carrl_heading(k); break;
+        }
+        case CAO_POL_RVO: {
+            double out[2];
+            int n = e->nagents[w];
+            cao_orca_action(n, i, e->f[CAO_F_POS] + 2 * base, e->f[CAO_F_VEL] + 2 * base, e->goal + 2 * base,
+                            e->pref_speed + base, e->radius + base, e->f[CAO_F_HEADING][a], e->coop[a],
+                            e->cfg.dt, out);
+            a0 = out[0]; a1 = out[1]; break;
+        }
+    }
+    act[0] = (float)a0;
+    act[1] = (float)a1;
+}
+
+/* Agent.take_action (agent.py:147-190) with the dynamics models (dynamics/*.py) */
+static void take_action(cao_env* e, size_t a, const float* actf) {
+    double dt = e->cfg.dt;
+    uint8_t* U = e->u[CAO_U_IS_AT_GOAL];
+    if (U[a] || e->u[CAO_U_RAN_OUT_OF_TIME][a] || e->u[CAO_U_IN_COLLISION][a]) { /* agent.py:148-159 */
+        if (U[a]) e->u[CAO_U_WAS_AT_GOAL][a] = 1;
+        if (e->u[CAO_U_IN_COLLISION][a]) e->u[CAO_U_WAS_IN_COLLISION][a] = 1;
+        if (!U[a]) e->f[CAO_F_T][a] += dt;
+        e->f[CAO_F_VEL][2 * a] = e->f[CAO_F_VEL][2 * a + 1] = 0.0;
+        return;
+    }
+    double a0 = (double)actf[0], a1 = (double)actf[1];
+    double* pa = e->f[CAO_F_PAST_ACTIONS] + 4 * a; /* agent.py:162-163 */
+    pa[2] = pa[0]; pa[3] = pa[1]; pa[0] = a0; pa[1] = a1;
+    double h = e->f[CAO_F_HEADING][a];
+    double speed, hn;
+    double* vel = e->f[CAO_F_VEL] + 2 * a;
+    switch (e->dyn[a]) {
+        default:
+        case CAO_DYN_UNICYCLE: /* UnicycleDynamics.py:10-24 */
+            speed = a0; hn = wrap(a1 + h); break;
+        case CAO_DYN_MAXTURNRATE: { /* UnicycleDynamicsMaxTurnRate.py:11-25 */
+            double tr = clipd(a1 / dt, -3.0, 3.0);
+            speed = a0; hn = wrap(tr * dt + h); break;
+        }
+        case CAO_DYN_MAXACC: { /* UnicycleDynamicsMaxAcc.py:17-39 */
+            double tr = clipd(a1 / dt, -3.0, 3.0);
+            double lacc = clipd(2.0 * (a0 - e->cur_speed[a]), -2.0, 2.0);
+            double tacc = clipd(2.0 * (tr - e->cur_turn[a]), -3.0, 3.0);
+            e->cur_speed[a] += lacc * dt;
+            e->cur_speed[a] = clipd(e->cur_speed[a], -1.1, 1.1);
+            e->cur_turn[a] += tacc * dt;
+            speed = e->cur_speed[a]; hn = wrap(e->cur_turn[a] * dt + h); break;
+        }
+        case CAO_DYN_SECONDORDER: { /* UnicycleSecondOrderEulerDynamics.py:12-29 */
+            speed = clipd(norm2(vel[0], vel[1]) + a0 * dt, 0.0, 1.0);
+            double tr = e->ang_speed[a] + a1 * dt;
+            e->ang_speed[a] = clipd(tr, -3.0, 3.0);
+            hn = wrap(e->ang_speed[a] * dt + h); break;
+        }
+        case CAO_DYN_FIRSTORDER: /* FirstOrderDynamics.py:10-23 */
+            speed = a0; hn = wrap(a1 * dt + h); break;
+    }
+    double c = cos(hn), s = sin(hn);
+    double dx = speed * c * dt, dy = speed * s * dt;
+    e->f[CAO_F_POS][2 * a] += dx;
+    e->f[CAO_F_POS][2 * a + 1] += dy;
+    vel[0] = speed * c; vel[1] = speed * s;
+    e->f[CAO_F_SPEED][a] = speed;
+    e->f[CAO_F_DELTA_HEADING][a] = wrap(hn - h);
+    e->f[CAO_F_HEADING][a] = hn;
+    update_ego_frame(e, a);
+    /* end_conditions._check_if_at_goal (utils/end_conditions.py:3-6) */
+    double ex = e->f[CAO_F_POS][2 * a] - e->goal[2 * a], ey = e->f[CAO_F_POS][2 * a + 1] - e->goal[2 * a + 1];
+    U[a] = ex * ex + ey * ey <= 0.75 * 0.75;
+    e->f[CAO_F_TIME_REMAINING][a] -= dt; /* agent.py:184-188 */
+    e->f[CAO_F_T][a] += dt;
+    e->i32[CAO_I_STEP_NUM][a] += 1;
+    if (e->f[CAO_F_TIME_REMAINING][a] <= 0.0) e->u[CAO_U_RAN_OUT_OF_TIME][a] = 1;
+}
+
+/* _compute_rewards + _check_for_collisions (env.py:502-567, 630-671) */
+static void rewards_world(cao_env* e, int w) {
+    int M = e->M, n = e->nagents[w];
+    size_t base = (size_t)w * M;
+    uint8_t coll_agent[64] = {0}, coll_wall[64] = {0};
+    double dmin[64];
+    for (int i = 0; i < n; i++) dmin[i] = INFINITY;
+    const double* P = e->f[CAO_F_POS];
+    for (int i = 0; i < n; i++)
+        for (int j = i + 1; j < n; j++) {
+            if (e->policy[base + j] == CAO_POL_STATIC && !e->cfg.collide_with_static) continue; /* env.py:643 (Q8) */
+            double d = norm2(P[2 * (base + i)] - P[2 * (base + j)], P[2 * (base + i) + 1] - P[2 * (base + j) + 1]);
+            double cr = e->radius[base + i] + e->radius[base + j];
+            double g = d - cr;
+            if (g < dmin[i]) dmin[i] = g; /* index i only (Q7) */
+            if (d <= cr) coll_agent[i] = coll_agent[j] = 1;
+        }
+    if (e->nobst[w] > 0) { /* env.py:656-666 */
+        const uint8_t* map = e->u[CAO_U_MAP] + (size_t)w * MAPD * MAPD;
+        for (int i = 0; i < n; i++) {
+            int pi, pj;
+            int in_map = world_to_cell(P[2 * (base + i)], P[2 * (base + i) + 1], &pi, &pj);
+            if (!in_map) continue;
+            double rr = e->radius[base + i] / 0.1, r2 = rr * rr;
+            int R = (int)ceil(rr) + 1, hit = 0;
+            for (int y = pi - R; y <= pi + R && !hit; y++)
+                for (int x = pj - R; x <= pj + R; x++) {
+                    if (y < 0 || x < 0 || y >= MAPD || x >= MAPD) continue;
+                    double dx = (double)(x - pj), dy = (double)(y - pi);
+                    if (dx * dx + dy * dy < r2 && map[y * MAPD + x]) { hit = 1; break; }
+                }
+            coll_wall[i] = (uint8_t)hit;
+        }
+    }
+    for (int i = 0; i < n; i++) {
+        size_t a = base + i;
+        double r = -0.01;
+        if (e->u[CAO_U_IS_AT_GOAL][a]) {
+            if (!e->u[CAO_U_WAS_AT_GOAL][a]) r = 3.0;
+        } else {
+            if (!e->u[CAO_U_WAS_IN_COLLISION][a]) {
+                if (coll_agent[i]) { r = -10.0; e->u[CAO_U_IN_COLLISION][a] = 1; }
+                else if (coll_wall[i]) { r = -0.25; e->u[CAO_U_IN_COLLISION][a] = 1; }
+                else {
+                    if (dmin[i] <= 0.2) r += -0.1 - dmin[i] / 2.;
+                    /* wiggly-behaviour term: threshold 0.0, value 0.0 (config.py:41-42) -> += 0.0 */
+                    const double* pa = e->f[CAO_F_PAST_ACTIONS] + 4 * a;
+                    if (norm2(pa[2] - pa[0], pa[3] - pa[1]) > 0.0) r += 0.0;
+                }
+            } else if (e->u[CAO_U_RAN_OUT_OF_TIME][a]) {
+                r += -10.0; /* Q9: reachable only after a collision */
+            }
+            r += 0.0 * (e->f[CAO_F_PAST_DIST_TO_GOAL][a] - e->f[CAO_F_DIST_TO_GOAL][a]); /* env.py:561 */
+        }
+        r = clipd(r, -10.0, 3.0) / (3.0 - (-10.0)); /* env.py:563-564 */
+        e->f[CAO_F_REWARD][a] = r;
+    }
+}
+
+/* _check_which_agents_done (env.py:711-738) */
+static void done_world(cao_env* e, int w) {
+    int n = e->nagents[w];
+    size_t base = (size_t)w * e->M;
+    int all = 1, all_learning = 1;
+    for (int i = 0; i < n; i++) {
+        size_t a = base + i;
+        uint8_t d = e->u[CAO_U_IS_AT_GOAL][a] | e->u[CAO_U_RAN_OUT_OF_TIME][a] | e->u[CAO_U_IN_COLLISION][a];
+        e->u[CAO_U_IS_DONE][a] = d;
+        all &= d;
+        if (e->policy[a] == CAO_POL_LEARNING) all_learning &= d;
+    }
+    uint8_t go;
+    switch (e->cfg.game_over_mode) {
+        case CAO_GO_ALL: go = (uint8_t)all; break;
+        case CAO_GO_LEARNING: go = (uint8_t)all_learning; break;
+        default: go = n > 0 ? e->u[CAO_U_IS_DONE][base] : 1; break;
+    }
+    e->u[CAO_U_GAME_OVER][w] = go;
+}
+
+void cao_step(cao_env* e, const double* ext_actions) {
+    float act[64][2];
+    for (int w = 0; w < e->N; w++) {
+        int n = e->nagents[w];
+        size_t base = (size_t)w * e->M;
+        for (int i = 0; i < n; i++) select_action(e, w, i, ext_actions, act[i]); /* all select first ... */
+        for (int i = 0; i < n; i++) {                                            /* ... then all move (env.py:334-335) */
+            e->f[CAO_F_ACTION][2 * (base + i)] = act[i][0];
+            e->f[CAO_F_ACTION][2 * (base + i) + 1] = act[i][1];
+            take_action(e, base + i, act[i]);
+        }
+        rewards_world(e, w);
+        sense_world(e, w);
+        done_world(e, w);
+    }
+}

@@ -1,0 +1,83 @@
+/* cagym_oracle.h -- CPU restatement of the reference env.step() hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is the parity oracle: a plain-C, scalar, fp64
+ * restatement of gym_collision_avoidance's CollisionAvoidanceEnv.step()/reset()
+ * (reference file:line cited at every function in cagym_oracle.c).  It is pinned
+ * against golden vectors produced by executing the reference itself
+ * (tests/golden/make_golden.py -> tests/golden/ npz files).  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it; the
+ * product (libcagym_hip.so) never links, loads or falls back to it.
+ *
+ * Parity status: core path (a0-a11, a16) PINNED by reference-generated vectors;
+ * ORCA (a12) and GA3C network (a13) "parity unpinned" (third-party rvo2 /
+ * TensorFlow absent; restated from the published algorithm).
+ */
+#ifndef CAGYM_ORACLE_H
+#define CAGYM_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* policy / dynamics ids (same numbering as include/cagym.h) */
+enum { CAO_POL_STATIC = 0, CAO_POL_NONCOOP = 1, CAO_POL_EXTERNAL = 2, CAO_POL_LEARNING = 3,
+       CAO_POL_CARRL = 4, CAO_POL_RVO = 5, CAO_POL_GA3C = 6, CAO_POL_IGMCTS = 7 };
+enum { CAO_DYN_UNICYCLE = 0, CAO_DYN_MAXTURNRATE = 1, CAO_DYN_MAXACC = 2, CAO_DYN_SECONDORDER = 3,
+       CAO_DYN_FIRSTORDER = 4 };
+
+/* game_over rule (collision_avoidance_env.py:722-736) */
+enum { CAO_GO_AGENT0 = 0,      /* EVALUATE&&!HOMOGENEOUS, or TRAIN_SINGLE_AGENT: done[0]       */
+       CAO_GO_ALL = 1,         /* EVALUATE&&HOMOGENEOUS: all(done)                            */
+       CAO_GO_LEARNING = 2 };  /* training, multi-agent: all learning agents done (all([])=1) */
+
+typedef struct {
+    int32_t n_worlds;          /* N */
+    int32_t max_agents;        /* M: agent slots per world (Config.MAX_NUM_AGENTS_IN_ENVIRONMENT) */
+    int32_t max_obstacles;     /* K rectangles per world (0 = free space) */
+    int32_t game_over_mode;    /* CAO_GO_* */
+    int32_t collide_with_static; /* Config.COLLISION_AV_W_STATIC_AGENT (config.py:52) */
+    int32_t laserscan;         /* 1: agents carry LaserScanSensor */
+    double dt;                 /* Config.DT (config.py:29) */
+} cao_config;
+
+typedef struct cao_env cao_env;
+
+cao_env* cao_create(const cao_config* cfg);
+void cao_destroy(cao_env* e);
+
+/* agents6[N,M,6] = sx,sy,gx,gy,pref_speed,radius; heading0[N,M] or NULL (toward goal,
+ * agent.py:29-31); policy_id/dynamics_id[N,M]; n_agents[N] or NULL (=M);
+ * coop[N,M] or NULL (1.0, agent.py:10); obstacles[N,K,4] = xl,yl,xu,yu; n_obst[N]. */
+void cao_set_scenario(cao_env* e, const double* agents6, const double* heading0, const int32_t* policy_id,
+                      const int32_t* dynamics_id, const int32_t* n_agents, const double* coop,
+                      const double* obstacles, const int32_t* n_obst);
+/* world_mask[N] (NULL = all): re-initialise the masked worlds from the scenario and sense. */
+void cao_reset(cao_env* e, const uint8_t* world_mask);
+/* ext_actions[N,M,2] doubles (may be NULL when no agent needs one). */
+void cao_step(cao_env* e, const double* ext_actions);
+
+/* zero-copy views for the tests; field ids below */
+enum { CAO_F_POS = 0, CAO_F_VEL, CAO_F_HEADING, CAO_F_SPEED, CAO_F_DELTA_HEADING, CAO_F_DIST_TO_GOAL,
+       CAO_F_PAST_DIST_TO_GOAL, CAO_F_HEADING_EGO, CAO_F_VEL_EGO, CAO_F_REF_PRLL, CAO_F_REL_GOAL,
+       CAO_F_TIME_REMAINING, CAO_F_T, CAO_F_PAST_ACTIONS, CAO_F_REWARD, CAO_F_OAS, CAO_F_LASERSCAN,
+       CAO_F_ACTION, CAO_F_COUNT };
+enum { CAO_U_IS_AT_GOAL = 0, CAO_U_WAS_AT_GOAL, CAO_U_IN_COLLISION, CAO_U_WAS_IN_COLLISION,
+       CAO_U_RAN_OUT_OF_TIME, CAO_U_IS_DONE, CAO_U_GAME_OVER, CAO_U_MAP, CAO_U_COUNT };
+enum { CAO_I_STEP_NUM = 0, CAO_I_NUM_OBSERVED, CAO_I_COUNT };
+double* cao_f64(cao_env* e, int field);
+uint8_t* cao_u8(cao_env* e, int field);
+int32_t* cao_i32(cao_env* e, int field);
+
+/* ---- stand-alone primitives (also used by the env above) ---- */
+/* Map.get_occupancy_grid (Map.py:107-123): 300x300 u8 raster from rectangles. */
+void cao_rasterize(const double* obstacles, int n_obst, uint8_t* map300);
+/* ORCA ego solve (RVOPolicy.py:53-117 + RVO2 Agent::computeNewVelocity), fp32 inside. */
+void cao_orca_action(int M, int ego, const double* pos, const double* vel, const double* goal,
+                     const double* pref_speed, const double* radius, double heading, double collab,
+                     double dt, double* action_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

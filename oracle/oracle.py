@@ -1,0 +1,143 @@
+"""ctypes front-end of the parity oracle (TEST INFRASTRUCTURE ONLY).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "libcagym_oracle.so")
+
+F = dict(pos=0, vel=1, heading=2, speed=3, delta_heading=4, dist_to_goal=5, past_dist_to_goal=6,
+         heading_ego=7, vel_ego=8, ref_prll=9, rel_goal=10, time_remaining=11, t=12, past_actions=13,
+         reward=14, oas=15, laserscan=16, action=17)
+U = dict(is_at_goal=0, was_at_goal_already=1, in_collision=2, was_in_collision_already=3,
+         ran_out_of_time=4, is_done=5, game_over=6, map=7)
+I = dict(step_num=0, num_other_agents_observed=1)
+F_WIDTH = dict(pos=2, vel=2, heading=1, speed=1, delta_heading=1, dist_to_goal=1, past_dist_to_goal=1,
+               heading_ego=1, vel_ego=2, ref_prll=2, rel_goal=2, time_remaining=1, t=1, past_actions=4,
+               reward=1, laserscan=16, action=2)
+GO_AGENT0, GO_ALL, GO_LEARNING = 0, 1, 2
+
+
+class Config(C.Structure):
+    _fields_ = [("n_worlds", C.c_int32), ("max_agents", C.c_int32), ("max_obstacles", C.c_int32),
+                ("game_over_mode", C.c_int32), ("collide_with_static", C.c_int32), ("laserscan", C.c_int32),
+                ("dt", C.c_double)]
+
+
+def build(force=False):
+    srcs = [os.path.join(HERE, f) for f in ("cagym_oracle.c", "cagym_oracle_ig.c", "cagym_oracle.h", "Makefile")]
+    if force or not os.path.exists(LIB) or any(os.path.getmtime(s) > os.path.getmtime(LIB) for s in srcs):
+        subprocess.check_call(["make", "-s", "-C", HERE, "libcagym_oracle.so"])
+    return LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            build()
+        L = C.CDLL(LIB)
+        L.cao_create.restype = C.c_void_p
+        L.cao_create.argtypes = [C.POINTER(Config)]
+        L.cao_destroy.argtypes = [C.c_void_p]
+        L.cao_set_scenario.argtypes = [C.c_void_p] + [C.c_void_p] * 8
+        L.cao_reset.argtypes = [C.c_void_p, C.c_void_p]
+        L.cao_step.argtypes = [C.c_void_p, C.c_void_p]
+        for n, t in (("cao_f64", C.c_double), ("cao_u8", C.c_uint8), ("cao_i32", C.c_int32)):
+            getattr(L, n).restype = C.POINTER(t)
+            getattr(L, n).argtypes = [C.c_void_p, C.c_int]
+        L.cao_rasterize.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.cao_orca_action.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_double] * 3 + [C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class OracleEnv(object):
+    """N worlds x M agent slots, fp64, scalar CPU."""
+
+    def __init__(self, N, M, max_obstacles=0, game_over_mode=GO_AGENT0, collide_with_static=False,
+                 laserscan=False, dt=0.1):
+        self.N, self.M, self.K, self.Kobs = N, M, M - 1, max_obstacles
+        self.cfg = Config(N, M, max_obstacles, game_over_mode, int(collide_with_static), int(laserscan), dt)
+        self.L = lib()
+        self.h = self.L.cao_create(C.byref(self.cfg))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.cao_destroy(self.h)
+            self.h = None
+
+    def set_scenario(self, agents6, policy_id, dynamics_id, heading0=None, n_agents=None, coop=None,
+                     obstacles=None, n_obst=None):
+        N, M = self.N, self.M
+        a6 = np.ascontiguousarray(np.asarray(agents6, dtype=np.float64).reshape(N, M, 6))
+        pol = np.ascontiguousarray(np.broadcast_to(np.asarray(policy_id, dtype=np.int32), (N, M)))
+        dyn = np.ascontiguousarray(np.broadcast_to(np.asarray(dynamics_id, dtype=np.int32), (N, M)))
+        h0 = None if heading0 is None else np.ascontiguousarray(np.asarray(heading0, dtype=np.float64).reshape(N, M))
+        na = None if n_agents is None else np.ascontiguousarray(np.asarray(n_agents, dtype=np.int32).reshape(N))
+        co = None if coop is None else np.ascontiguousarray(np.asarray(coop, dtype=np.float64).reshape(N, M))
+        ob = no = None
+        if obstacles is not None and self.Kobs:
+            ob = np.zeros((N, self.Kobs, 4), dtype=np.float64)
+            o = np.asarray(obstacles, dtype=np.float64)
+            ob[:, :o.shape[-2], :] = o.reshape(N, -1, 4)
+            no = np.ascontiguousarray(np.asarray(n_obst, dtype=np.int32).reshape(N))
+        self.L.cao_set_scenario(self.h, _p(a6), _p(h0), _p(pol), _p(dyn), _p(na), _p(co), _p(ob), _p(no))
+
+    def reset(self, world_mask=None):
+        m = None if world_mask is None else np.ascontiguousarray(np.asarray(world_mask, dtype=np.uint8))
+        self.L.cao_reset(self.h, _p(m))
+
+    def step(self, ext_actions=None):
+        a = None if ext_actions is None else np.ascontiguousarray(
+            np.asarray(ext_actions, dtype=np.float64).reshape(self.N, self.M, 2))
+        self.L.cao_step(self.h, _p(a))
+
+    def f(self, name):
+        w = self.K * 10 if name == "oas" else F_WIDTH[name]
+        arr = np.ctypeslib.as_array(self.L.cao_f64(self.h, F[name]), shape=(self.N * self.M * w,))
+        if name == "oas":
+            return arr.reshape(self.N, self.M, self.K, 10)
+        if name == "past_actions":
+            return arr.reshape(self.N, self.M, 2, 2)
+        return arr.reshape(self.N, self.M, w) if w > 1 else arr.reshape(self.N, self.M)
+
+    def u(self, name):
+        if name == "game_over":
+            return np.ctypeslib.as_array(self.L.cao_u8(self.h, U[name]), shape=(self.N,))
+        if name == "map":
+            return np.ctypeslib.as_array(self.L.cao_u8(self.h, U[name]), shape=(self.N, 300, 300))
+        return np.ctypeslib.as_array(self.L.cao_u8(self.h, U[name]), shape=(self.N, self.M))
+
+    def i(self, name):
+        return np.ctypeslib.as_array(self.L.cao_i32(self.h, I[name]), shape=(self.N, self.M))
+
+
+def rasterize(obstacles):
+    o = np.ascontiguousarray(np.asarray(obstacles, dtype=np.float64).reshape(-1, 4))
+    out = np.zeros((300, 300), dtype=np.uint8)
+    lib().cao_rasterize(_p(o), o.shape[0], _p(out))
+    return out
+
+
+def orca_action(pos, vel, goal, pref_speed, radius, ego, heading, collab=0.5, dt=0.1):
+    pos = np.ascontiguousarray(pos, dtype=np.float64)
+    vel = np.ascontiguousarray(vel, dtype=np.float64)
+    goal = np.ascontiguousarray(goal, dtype=np.float64)
+    ps = np.ascontiguousarray(pref_speed, dtype=np.float64)
+    rd = np.ascontiguousarray(radius, dtype=np.float64)
+    out = np.zeros(2)
+    lib().cao_orca_action(pos.shape[0], ego, _p(pos), _p(vel), _p(goal), _p(ps), _p(rd), float(heading),
+                          float(collab), float(dt), _p(out))
+    return out

@@ -1,0 +1,340 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by EXECUTING the reference env (this container only).
+
+Run:  python tests/golden/make_golden.py   (needs /root/reference; ~1 min)
+Output: tests/golden/*.npz  -- pure data (inputs + expected outputs per step).
+
+The reference is imported unmodified through tests/golden/ref_harness.py
+(SURVEY.md Appendix C).  Harness conventions, all documented in DESIGN.md:
+  * Config.DT = np.float64(0.1) and np.float64 initial headings: the reference was
+    written for NumPy 1.x (TensorFlow 1.15 pin, requirements.txt:1) where
+    np.float32-scalar (op) python-float promotes to float64.  Under NumPy >= 2
+    (NEP 50) the same expressions would stay float32; passing np.float64 operands
+    makes NumPy 2.2 reproduce the NumPy-1.x arithmetic the reference intends.
+  * D1 (set_agents honoured), D2 (no ig_mcts agent -> no-op), D4 (policy.targetMap=None).
+  * ExternalRaw: an ExternalPolicy whose convert_to_action is the identity.
+  * LearningD3: LearningPolicy called as (agent, actions[i]).
+Every case is stepped past game_over until all agents are done (+ a few steps) so
+the done-agent branch of Agent.take_action (agent.py:148-159) is covered.
+"""
+import os, sys, json
+import importlib
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, REPO)
+import ref_harness as rh
+
+rh.install_standins()
+from gym_collision_avoidance.envs.config import Config  # noqa: E402
+
+Config.ANIMATE_EPISODES = False
+Config.DT = np.float64(0.1)
+OBS_KEYS = ['dist_to_goal', 'rel_goal', 'radius', 'heading_ego_frame', 'pref_speed', 'other_agents_states']
+Config.STATES_IN_OBS = list(OBS_KEYS)
+
+with rh.quiet():
+    from gym_collision_avoidance.envs import test_cases as tc
+    from gym_collision_avoidance.envs.agent import Agent
+    from gym_collision_avoidance.envs.policies.StaticPolicy import StaticPolicy
+    from gym_collision_avoidance.envs.policies.NonCooperativePolicy import NonCooperativePolicy
+    from gym_collision_avoidance.envs.policies.ExternalPolicy import ExternalPolicy
+    from gym_collision_avoidance.envs.policies.LearningPolicy import LearningPolicy
+    from gym_collision_avoidance.envs.policies.CARRLPolicy import CARRLPolicy
+    from gym_collision_avoidance.envs.dynamics.UnicycleDynamics import UnicycleDynamics
+    from gym_collision_avoidance.envs.dynamics.UnicycleDynamicsMaxTurnRate import UnicycleDynamicsMaxTurnRate
+    from gym_collision_avoidance.envs.dynamics.UnicycleDynamicsMaxAcc import UnicycleDynamicsMaxAcc
+    from gym_collision_avoidance.envs.dynamics.UnicycleSecondOrderEulerDynamics import UnicycleSecondOrderEulerDynamics
+    from gym_collision_avoidance.envs.dynamics.FirstOrderDynamics import FirstOrderDynamics
+    from gym_collision_avoidance.envs.sensors.OtherAgentsStatesSensor import OtherAgentsStatesSensor
+    from gym_collision_avoidance.envs.sensors.LaserScanSensor import LaserScanSensor
+    OracleEnv = rh.make_oracle_env_class()
+
+scen = importlib.import_module("gym-exploration-2d_amd.scenarios")
+
+
+class ExternalRaw(ExternalPolicy):
+    def __init__(self):
+        ExternalPolicy.__init__(self, str="ExternalRaw")
+
+    def convert_to_action(self, a):
+        return a
+
+
+class LearningD3(LearningPolicy):
+    def network_output_to_action(self, idx, agents, actions):
+        return LearningPolicy.network_output_to_action(self, agents[idx], actions[idx])
+
+
+POLICIES = {scen.POLICY_STATIC: StaticPolicy, scen.POLICY_NONCOOP: NonCooperativePolicy,
+            scen.POLICY_EXTERNAL: ExternalRaw, scen.POLICY_LEARNING: LearningD3,
+            scen.POLICY_CARRL: CARRLPolicy}
+DYNAMICS = {scen.DYN_UNICYCLE: UnicycleDynamics, scen.DYN_MAXTURNRATE: UnicycleDynamicsMaxTurnRate,
+            scen.DYN_MAXACC: UnicycleDynamicsMaxAcc, scen.DYN_SECONDORDER: UnicycleSecondOrderEulerDynamics,
+            scen.DYN_FIRSTORDER: FirstOrderDynamics}
+
+
+def set_max_agents(m):
+    """patch the derived sizes consistently."""
+    Config.MAX_NUM_AGENTS_IN_ENVIRONMENT = m
+    Config.MAX_NUM_OTHER_AGENTS_IN_ENVIRONMENT = m - 1
+    Config.MAX_NUM_OTHER_AGENTS_OBSERVED = m - 1
+    Config.STATE_INFO_DICT['other_agents_states']['size'] = (m - 1, 10)
+
+
+def rect(xl, yl, xu, yu):
+    """Obstacle corner order of test_cases.py:2496."""
+    return [(xu, yu), (xl, yu), (xl, yl), (xu, yl)]
+
+
+def snapshot(env, rec, rewards, game_over, laser):
+    A = env.agents
+    f = lambda name: np.array([float(getattr(a, name)) for a in A])
+    v = lambda name: np.array([np.asarray(getattr(a, name), dtype=np.float64) for a in A])
+    b = lambda name: np.array([bool(getattr(a, name)) for a in A])
+    rec['pos'].append(v('pos_global_frame'))
+    rec['vel'].append(v('vel_global_frame'))
+    rec['heading'].append(f('heading_global_frame'))
+    rec['speed'].append(f('speed_global_frame'))
+    rec['delta_heading'].append(f('delta_heading_global_frame'))
+    rec['dist_to_goal'].append(f('dist_to_goal'))
+    rec['past_dist_to_goal'].append(f('past_dist_to_goal'))
+    rec['heading_ego'].append(f('heading_ego_frame'))
+    rec['vel_ego'].append(v('vel_ego_frame'))
+    rec['ref_prll'].append(v('ref_prll'))
+    rec['rel_goal'].append(v('rel_goal'))
+    rec['time_remaining'].append(f('time_remaining_to_reach_goal'))
+    rec['t'].append(f('t'))
+    rec['step_num'].append(np.array([int(a.step_num) for a in A]))
+    rec['past_actions'].append(v('past_actions'))
+    rec['is_at_goal'].append(b('is_at_goal'))
+    rec['was_at_goal_already'].append(b('was_at_goal_already'))
+    rec['in_collision'].append(b('in_collision'))
+    rec['was_in_collision_already'].append(b('was_in_collision_already'))
+    rec['ran_out_of_time'].append(b('ran_out_of_time'))
+    rec['is_done'].append(b('is_done'))
+    rec['num_other_agents_observed'].append(np.array([int(a.num_other_agents_observed) for a in A]))
+    rec['oas'].append(np.array([np.asarray(a.sensor_data['other_agents_states'], dtype=np.float64) for a in A]))
+    if laser:
+        rec['laserscan'].append(np.array([np.asarray(a.sensor_data['laserscan'], dtype=np.float64) for a in A]))
+    rec['reward'].append(np.asarray(rewards, dtype=np.float64) * np.ones(len(A)))
+    rec['game_over'].append(bool(game_over))
+
+
+def run_case(agents6, policy_id, dynamics_id, heading0=None, obstacles=(), laser=False,
+             ext_actions=None, max_steps=220, extra=3, evaluate=True, homogeneous=False,
+             single=False, m_max=10):
+    agents6 = np.asarray(agents6, dtype=np.float64)
+    M = agents6.shape[0]
+    policy_id = np.broadcast_to(np.asarray(policy_id), (M,)).astype(np.int32)
+    dynamics_id = np.broadcast_to(np.asarray(dynamics_id), (M,)).astype(np.int32)
+    if heading0 is None:
+        heading0 = scen.heading_toward_goal(agents6)
+    heading0 = np.asarray(heading0, dtype=np.float64)
+    set_max_agents(m_max)
+    Config.EVALUATE_MODE = evaluate
+    Config.HOMOGENEOUS_TESTING = homogeneous
+    Config.TRAIN_SINGLE_AGENT = False  # rewards for all M agents; scalar mode is rewards[0] (env.py:565-566)
+    sensors = [OtherAgentsStatesSensor] + ([LaserScanSensor] if laser else [])
+    with rh.quiet():
+        agents = [Agent(agents6[i, 0], agents6[i, 1], agents6[i, 2], agents6[i, 3], agents6[i, 5], agents6[i, 4],
+                        np.float64(heading0[i]), POLICIES[int(policy_id[i])], DYNAMICS[int(dynamics_id[i])],
+                        sensors, i) for i in range(M)]
+        for a in agents:
+            a.policy.targetMap = None
+        env = OracleEnv()
+        env.oracle_obstacles = [rect(*o) for o in obstacles]
+        env.set_agents(agents)
+        env.reset()
+    # game_over rule under test (env.py:722-736); TRAIN_SINGLE_AGENT only affects game_over here
+    Config.TRAIN_SINGLE_AGENT = single
+    keys = ['pos', 'vel', 'heading', 'speed', 'delta_heading', 'dist_to_goal', 'past_dist_to_goal', 'heading_ego',
+            'vel_ego', 'ref_prll', 'rel_goal', 'time_remaining', 't', 'step_num', 'past_actions', 'is_at_goal',
+            'was_at_goal_already', 'in_collision', 'was_in_collision_already', 'ran_out_of_time', 'is_done',
+            'num_other_agents_observed', 'oas', 'reward', 'game_over'] + (['laserscan'] if laser else [])
+    rec = {k: [] for k in keys}
+    snapshot(env, rec, np.zeros(M), False, laser)
+    T = max_steps if ext_actions is None else min(max_steps, len(ext_actions))
+    after = None
+    used = []
+    for s in range(T):
+        if ext_actions is None:
+            acts = {}
+        else:
+            acts = {i: (int(ext_actions[s, i, 0]) if policy_id[i] == scen.POLICY_CARRL else ext_actions[s, i])
+                    for i in range(M)}
+        # rewards for all agents: the reference slices rewards[0] only when TRAIN_SINGLE_AGENT
+        Config.TRAIN_SINGLE_AGENT = False
+        with rh.quiet():
+            # compute game_over under the requested mode without changing rewards
+            orig = env._check_which_agents_done
+
+            def patched():
+                Config.TRAIN_SINGLE_AGENT = single
+                try:
+                    return orig()
+                finally:
+                    Config.TRAIN_SINGLE_AGENT = False
+            env._check_which_agents_done = patched
+            _, rewards, game_over, info = env.step(acts)
+            env._check_which_agents_done = orig
+        snapshot(env, rec, rewards, game_over, laser)
+        used.append(s)
+        if all(a.is_done for a in env.agents):
+            after = extra if after is None else after - 1
+            if after == 0:
+                break
+    out = {k: np.array(v) for k, v in rec.items()}
+    out['agents6'] = agents6
+    out['heading0'] = heading0
+    out['policy_id'] = policy_id
+    out['dynamics_id'] = dynamics_id
+    out['obstacles'] = np.asarray(obstacles, dtype=np.float64).reshape(-1, 4)
+    if ext_actions is not None:
+        out['ext_actions'] = np.asarray(ext_actions[:len(used)], dtype=np.float64)
+    out['cfg'] = np.array([int(evaluate), int(homogeneous), int(single), int(m_max), int(laser)], dtype=np.int32)
+    return out
+
+
+def save(group, cases):
+    flat = {}
+    for name, c in cases.items():
+        for k, v in c.items():
+            flat[name + "__" + k] = v
+    path = os.path.join(HERE, group + ".npz")
+    np.savez_compressed(path, **flat)
+    print("%-28s %3d cases %8.1f KB" % (group, len(cases), os.path.getsize(path) / 1024))
+
+
+def f32exact(x):
+    return np.asarray(x, dtype=np.float32).astype(np.float64)
+
+
+def main():
+    rng = np.random.default_rng(20250222)
+    U, NC, ST = scen.DYN_UNICYCLE, scen.POLICY_NONCOOP, scen.POLICY_STATIC
+
+    # A. preset_testCases (test_cases.py:2035-2199), NonCooperative / Unicycle
+    cases = {}
+    for n in (2, 3, 4, 5, 6):
+        with rh.quiet():
+            P = tc.preset_testCases(n)
+        for ci, case in enumerate(P):
+            cases["n%d_c%d" % (n, ci)] = run_case(case, NC, U)
+    save("presets_noncoop", cases)
+
+    cases = {}
+    with rh.quiet():
+        P10 = tc.preset_testCases(10)
+    for ci, case in enumerate(P10[:2]):
+        cases["n10_c%d" % ci] = run_case(case, NC, U, homogeneous=True)
+    with rh.quiet():
+        P20 = tc.preset_testCases(20)
+    cases["n20_c0"] = run_case(P20[0], NC, U, m_max=20, homogeneous=True, max_steps=120)
+    save("presets_large", cases)
+
+    # B. Static / NonCooperative mixes: Q8 (static as pair member j), Q9 (timeout reward), timeouts
+    cases = {}
+    with rh.quiet():
+        P4, P6 = tc.preset_testCases(4), tc.preset_testCases(6)
+    cases["n4_static_odd"] = run_case(P4[6 if len(P4) > 6 else 0], [NC, ST, NC, ST], U, homogeneous=True)
+    cases["n4_static_even"] = run_case(P4[6 if len(P4) > 6 else 0], [ST, NC, ST, NC], U, homogeneous=True)
+    cases["n6_static_mix"] = run_case(P6[0], [NC, NC, ST, NC, ST, NC], U, homogeneous=True)
+    # a static agent parked on a NonCooperative agent's path: collision with static as member i and j
+    blk = np.array([[-3, 0, 3, 0, 1.0, 0.5], [0, 0.2, 5, 5, 1.0, 0.5], [3, 0.1, -3, 0.1, 1.0, 0.4]])
+    cases["n3_static_block_j"] = run_case(blk, [NC, ST, NC], U, homogeneous=True)
+    cases["n3_static_block_i"] = run_case(blk[[1, 0, 2]], [ST, NC, NC], U, homogeneous=True)
+    save("static_mixes", cases)
+
+    # A'/B'. the same presets with a seeded perturbation of starts/goals: the exact presets meet at
+    # ulp-level knife edges (d == r_i + r_j exactly), where the reference's own masks depend on
+    # libm rounding; the perturbed copies exercise collisions/goals/timeouts away from them.
+    cases = {}
+    pr = np.random.default_rng(31337)
+
+    def jitter(c):
+        c = np.array(c, dtype=np.float64)
+        c[:, 0:4] += pr.uniform(-0.07, 0.07, c[:, 0:4].shape)
+        return c
+    for n in (2, 3, 4, 5, 6):
+        with rh.quiet():
+            P = tc.preset_testCases(n)
+        for ci, case in enumerate(P):
+            cases["n%d_c%d" % (n, ci)] = run_case(jitter(case), NC, U, homogeneous=True)
+    save("presets_perturbed", cases)
+    cases = {}
+    cases["n4_static_odd"] = run_case(jitter(P4[6 if len(P4) > 6 else 0]), [NC, ST, NC, ST], U, homogeneous=True)
+    cases["n4_static_even"] = run_case(jitter(P4[6 if len(P4) > 6 else 0]), [ST, NC, ST, NC], U, homogeneous=True)
+    cases["n6_static_mix"] = run_case(jitter(P6[0]), [NC, NC, ST, NC, ST, NC], U, homogeneous=True)
+    cases["n3_static_block_j"] = run_case(jitter(blk), [NC, ST, NC], U, homogeneous=True)
+    cases["n3_static_block_i"] = run_case(jitter(blk[[1, 0, 2]]), [ST, NC, NC], U, homogeneous=True)
+    cases["n10_circle"] = run_case(jitter(P10[0]), NC, U, homogeneous=True)
+    save("static_mixes_perturbed", cases)
+
+    # C. dynamics variants with external raw actions and with NonCooperative
+    cases = {}
+    for dname, d in (("maxturn", scen.DYN_MAXTURNRATE), ("maxacc", scen.DYN_MAXACC),
+                     ("second", scen.DYN_SECONDORDER), ("first", scen.DYN_FIRSTORDER), ("uni", scen.DYN_UNICYCLE)):
+        w = scen.random_world(np.random.default_rng(77), 4)
+        T = 60
+        acts = np.stack([rng.uniform(-0.2, 1.2, (T, 4)), rng.uniform(-1.0, 1.0, (T, 4))], axis=-1)
+        cases["ext_" + dname] = run_case(w, scen.POLICY_EXTERNAL, d, ext_actions=f32exact(acts), max_steps=T)
+        cases["nc_" + dname] = run_case(P4[2], NC, d, max_steps=80, homogeneous=True)
+    save("dynamics_variants", cases)
+
+    # D. action maps: Learning (D3), CARRL table, mixes; game_over modes
+    cases = {}
+    w = scen.random_world(np.random.default_rng(5), 4)
+    T = 70
+    u = np.stack([rng.uniform(0, 1, (T, 4)), rng.uniform(0.35, 0.65, (T, 4))], axis=-1)
+    cases["learning_train"] = run_case(w, scen.POLICY_LEARNING, U, ext_actions=f32exact(u), max_steps=T,
+                                       evaluate=False, single=False,
+                                       heading0=rng.uniform(-np.pi, np.pi, 4))
+    cases["learning_single"] = run_case(w, [scen.POLICY_LEARNING, NC, NC, ST], U, ext_actions=f32exact(u),
+                                        max_steps=T, evaluate=False, single=True)
+    cases["learning_mixed_train"] = run_case(w, [NC, scen.POLICY_LEARNING, ST, scen.POLICY_LEARNING], U,
+                                             ext_actions=f32exact(u), max_steps=T, evaluate=False, single=False)
+    d = np.stack([rng.integers(0, 11, (T, 4)).astype(np.float64), np.zeros((T, 4))], axis=-1)
+    cases["carrl"] = run_case(w, [scen.POLICY_CARRL, NC, scen.POLICY_CARRL, NC], U, ext_actions=d, max_steps=T)
+    save("action_maps", cases)
+
+    # E. random free-space worlds (SURVEY 8(d) rule), NonCooperative, game_over = all done
+    cases = {}
+    for wi in range(6):
+        cases["m4_w%d" % wi] = run_case(scen.random_world(np.random.default_rng(1234 + wi), 4), NC, U,
+                                        homogeneous=True)
+    for wi in range(3):
+        cases["m10_w%d" % wi] = run_case(scen.random_world(np.random.default_rng(1234 + wi), 10), NC, U,
+                                         homogeneous=True)
+    save("random_worlds", cases)
+
+    # F. obstacles: rasteriser, wall collision, LaserScan (Map.py, LaserScanSensor.py:27-58, env.py:656-666)
+    cases = {}
+    ig_obst = [(2, 2, 10, 10), (-10, 2, -2, 10), (2, -10, 10, -2), (-10, -10, -2, -2)]  # test_cases.py:3219-3223
+    corridor = np.array([[-5, 0, 12, 0, 1.0, 0.5], [0, 0, -12, 0.3, 1.0, 0.5], [5, 0.5, 5, 12, 1.0, 0.5],
+                         [0.3, -6, 8, 8, 1.0, 0.4]])
+    cases["ig_corridor_nc"] = run_case(corridor, NC, U, obstacles=ig_obst, laser=True, homogeneous=True,
+                                       max_steps=150)
+    rr = np.random.default_rng(99)
+    for wi in range(3):
+        obst = []
+        for _ in range(rr.integers(2, 6)):
+            cx, cy = rr.uniform(-9, 9, 2)
+            hw, hh = rr.uniform(0.3, 2.0, 2)
+            obst.append((round(cx - hw, 2), round(cy - hh, 2), round(cx + hw, 2), round(cy + hh, 2)))
+        w = scen.random_world(np.random.default_rng(4000 + wi), 5)
+        cases["rand_rect_w%d" % wi] = run_case(w, NC, U, obstacles=obst, laser=True, homogeneous=True,
+                                               max_steps=150)
+    # externally driven agents incl. leaving the 30x30 m map (in_map false branch, Map.py:45-47)
+    w = np.array([[13.5, 13.0, -5, 0, 1.0, 0.5], [-13.8, 0, 5, 0, 1.0, 0.3], [0, 14.2, 0, -5, 1.0, 0.5]])
+    T = 50
+    acts = np.stack([np.full((T, 3), 1.0), rng.uniform(-0.3, 0.3, (T, 3))], axis=-1)
+    cases["leave_map"] = run_case(w, scen.POLICY_EXTERNAL, U, heading0=[0.6, 3.0, 1.6], obstacles=ig_obst,
+                                  laser=True, ext_actions=f32exact(acts), max_steps=T)
+    save("obstacles_laserscan", cases)
+
+
+if __name__ == "__main__":
+    main()
