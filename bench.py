@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/sec of the batched CollisionAvoidanceEnv on N MI355X (BASELINE.json metric).
+
+Workload (N=1): BASELINE.json configs[2] -- 4096 worlds x 10 agents, every agent RVO/ORCA (ego LP on
+device) + OtherAgentsStates sensor, synthetic random-goal episodes (SURVEY.md 8(d) rule), auto-reset
+from a pool of 8x4096 scenarios.  One "step" = one env.step() of all worlds of a rank.  Steps are
+issued through cagym_rollout (ROLL env steps per launch, agent state in registers, every step writes
+its full observation / reward / flag tensors to HBM slice t of a trajectory buffer).
+
+Multi-GPU (--gpus N under torch.distributed.run): worlds are independent, each rank owns its own 4096
+worlds (weak scaling); the only collective is the RCCL all-gather of per-world episode statistics,
+issued once per rollout launch on a side stream.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+B_ALG = {"noncoop": 133.0 + 384.0, "rvo": 517.0}  # algorithmic bytes / agent-step
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(M, policy_id, seconds=12.0, worlds=128):
+    """The CPU restatement (oracle, "port") timed on this host: scalar, 1 core, bounded sample."""
+    from oracle import oracle as orc
+    scen = importlib.import_module("gym-exploration-2d_amd.scenarios")
+    orc.build()
+    a6 = scen.random_worlds_fast(worlds, M, seed=99)
+    env = orc.OracleEnv(N=worlds, M=M, game_over_mode=1)
+    env.set_scenario(a6, policy_id, scen.DYN_UNICYCLE, coop=np.full((worlds, M), 0.5))
+    env.reset()
+    steps = 0
+    t0 = time.perf_counter()
+    while True:
+        env.step()
+        steps += 1
+        go = env.u("game_over")
+        if go.any():
+            env.reset(world_mask=go)  # same scenario again: reset cost included, as in BASELINE.md
+        el = time.perf_counter() - t0
+        if el >= seconds:
+            break
+    return {"value": worlds * steps / el, "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "sample": "%d worlds x %d agents, %d steps, %.1f s, scalar C oracle (oracle/cagym_oracle.c), "
+                      "same policy/scenario rule" % (worlds, M, steps, el)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2048)
+    ap.add_argument("--warmup", type=int, default=256)
+    ap.add_argument("--worlds", type=int, default=4096, help="worlds per GPU")
+    ap.add_argument("--agents", type=int, default=10)
+    ap.add_argument("--policy", default="rvo", choices=["rvo", "noncoop"])
+    ap.add_argument("--roll", type=int, default=64, help="env steps per launch")
+    ap.add_argument("--per-step-launch", action="store_true", help="one cagym_step launch per env step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_size > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    scen = importlib.import_module("gym-exploration-2d_amd.scenarios")
+    stats_mod = importlib.import_module("gym-exploration-2d_amd.stats")
+    BEnv = importlib.import_module("gym-exploration-2d_amd.batched_env").BatchedCollisionAvoidanceEnv
+    N, M = args.worlds, args.agents
+    pol = scen.POLICY_RVO if args.policy == "rvo" else scen.POLICY_NONCOOP
+    S = 8 * N
+    a6 = scen.random_worlds_fast(S, M, seed=1234 + 7919 * rank)
+    env = BEnv(N, M, n_scenarios=S, game_over_mode="all", device=device)
+    env.set_scenarios(a6, pol, scen.DYN_UNICYCLE, coop=np.full((S, M), 0.5))
+    env.reset()
+
+    ROLL = max(1, min(args.roll, args.steps))
+    traj = env.alloc_rollout(ROLL)
+    side = torch.cuda.Stream(device=device) if world_size > 1 else None
+    gathered = None
+
+    def run(n_steps):
+        nonlocal gathered
+        done = 0
+        launches = 0
+        while done < n_steps:
+            k = min(ROLL, n_steps - done)
+            if args.per_step_launch:
+                for _ in range(k):
+                    _, _, go, _ = env.step()
+                    env.reset(world_mask=go, advance_episode=True)
+                    launches += 1
+            else:
+                env.rollout(k, auto_reset=True, out=traj)
+                launches += 1
+            done += k
+            if world_size > 1:
+                # episode-stats all-gather on a side stream, overlapping the next launch
+                local = stats_mod.pack_episode_stats(env.episode_stats())
+                side.wait_stream(torch.cuda.current_stream(device))
+                with torch.cuda.stream(side):
+                    gathered = stats_mod.all_gather_episode_stats(local)
+        if side is not None:
+            torch.cuda.current_stream(device).wait_stream(side)
+        return launches
+
+    def barrier():
+        if world_size > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    run(args.warmup)
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    launches = run(args.steps)
+    ev1.record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world_size > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    dev_ms = ev0.elapsed_time(ev1)
+
+    st = stats_mod.summarize(gathered if gathered is not None else stats_mod.pack_episode_stats(env.episode_stats()))
+    if rank == 0:
+        total_worlds = N * world_size
+        value = total_worlds * args.steps / elapsed
+        steps_per_launch = args.steps / launches
+        launch_ms = dev_ms / launches
+        balg = B_ALG[args.policy]
+        achieved = balg * N * M * steps_per_launch / (launch_ms * 1e-3) / 1e9
+        line = {
+            "metric": "env-steps/sec (whole node), 4096 worlds x 10 agents",
+            "value": value, "unit": "env-steps/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%d worlds x %d agents per GPU, %s policy + OtherAgentsStates sensor, "
+                                   "UnicycleDynamics, random-goal episodes with auto-reset (BASELINE configs[2])"
+                                   % (N, M, "RVO/ORCA on-device LP" if args.policy == "rvo" else "NonCooperative"),
+                       "worlds_per_gpu": N, "agents": M, "steps_per_launch": steps_per_launch,
+                       "launch_mode": "cagym_step per step" if args.per_step_launch else "cagym_rollout",
+                       "parallelism": "worlds sharded x%d, no data-path collective" % world_size},
+            "agent_steps_per_s": value * M,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_step+k_reset" if args.per_step_launch else "k_rollout<true>",
+                         "launch_ms": launch_ms, "alg_bytes_per_agent_step": balg},
+            "episodes": st,
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(M, pol)
+        print(json.dumps(line))
+    if world_size > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

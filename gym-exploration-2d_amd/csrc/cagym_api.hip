@@ -1,0 +1,272 @@
+// cagym_api.hip -- C ABI of libcagym_hip.so (include/cagym.h): handle, device buffers, launches.
+// No torch types, no CPU fallback: without a HIP device cagym_create fails.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/cagym.h"
+#include "cagym_kernels.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+struct Env {
+    cagym_config cfg;
+    CagymDev D;
+    std::vector<void*> allocs;
+    std::string err;
+    bool scenarios_set = false;
+    double* sc_obst = nullptr;
+    double* sc_heading_buf = nullptr;
+};
+
+int fail(Env* e, int code, const std::string& msg) {
+    g_last_error = msg;
+    if (e) e->err = msg;
+    return code;
+}
+
+#define HIPCHK(e, call)                                                                              \
+    do {                                                                                             \
+        hipError_t _s = (call);                                                                      \
+        if (_s != hipSuccess)                                                                        \
+            return fail(e, CAGYM_E_HIP, std::string(#call) + ": " + hipGetErrorString(_s));          \
+    } while (0)
+
+template <typename T>
+int dalloc(Env* e, T** p, size_t n) {
+    void* q = nullptr;
+    size_t bytes = (n ? n : 1) * sizeof(T);
+    hipError_t s = hipMalloc(&q, bytes);
+    if (s != hipSuccess) return fail(e, CAGYM_E_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(s));
+    s = hipMemset(q, 0, bytes);
+    if (s != hipSuccess) return fail(e, CAGYM_E_HIP, std::string("hipMemset: ") + hipGetErrorString(s));
+    e->allocs.push_back(q);
+    *p = reinterpret_cast<T*>(q);
+    return CAGYM_OK;
+}
+
+CagymOut to_out(const cagym_outputs* o) {
+    CagymOut r{};
+    if (o) {
+        r.obs_oas = o->obs_oas;
+        r.obs_ego = o->obs_ego;
+        r.laserscan = o->laserscan;
+        r.reward = o->reward;
+        r.flags = o->flags;
+        r.game_over = o->game_over;
+    }
+    return r;
+}
+
+inline int n_waves(const Env* e) {
+    int wpw = CAGYM_WAVE / e->cfg.max_agents;
+    return (e->cfg.n_worlds + wpw - 1) / wpw;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cagym_version(void) { return CAGYM_VERSION; }
+
+const char* cagym_last_error(void* env) {
+    Env* e = reinterpret_cast<Env*>(env);
+    return e ? e->err.c_str() : g_last_error.c_str();
+}
+
+int cagym_create(const cagym_config* cfg, void** env_out) {
+    if (!cfg || !env_out) return fail(nullptr, CAGYM_E_INVALID, "cagym_create: null argument");
+    *env_out = nullptr;
+    if (cfg->n_worlds < 1) return fail(nullptr, CAGYM_E_INVALID, "n_worlds must be >= 1");
+    if (cfg->max_agents < 2 || cfg->max_agents > 32)
+        return fail(nullptr, CAGYM_E_UNSUPPORTED, "max_agents must be in [2, 32] (a world may not straddle a wavefront)");
+    if (cfg->n_scenarios < cfg->n_worlds) return fail(nullptr, CAGYM_E_INVALID, "n_scenarios must be >= n_worlds");
+    if (cfg->max_obstacles < 0 || !(cfg->dt > 0)) return fail(nullptr, CAGYM_E_INVALID, "bad max_obstacles / dt");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(nullptr, CAGYM_E_NODEVICE, "no HIP device: libcagym_hip has no CPU fallback");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, CAGYM_E_INVALID, "device ordinal out of range");
+    Env* e = new Env();
+    e->cfg = *cfg;
+    HIPCHK(e, hipSetDevice(cfg->device));
+    CagymDev& D = e->D;
+    memset(&D, 0, sizeof(D));
+    const size_t N = cfg->n_worlds, M = cfg->max_agents, S = cfg->n_scenarios, NM = N * M, SM = S * M;
+    D.N = (int)N; D.M = (int)M; D.S = (int)S; D.Kobs = cfg->max_obstacles;
+    D.go_mode = cfg->game_over_mode; D.collide_static = cfg->collide_with_static; D.laserscan = cfg->laserscan;
+    D.dt = cfg->dt;
+    int rc = CAGYM_OK;
+    double* d6 = nullptr; double* dcoop = nullptr;
+    int32_t *dpol = nullptr, *ddyn = nullptr, *dna = nullptr, *dno = nullptr;
+    uint32_t* dmap = nullptr;
+#define A(call) if ((rc = (call)) != CAGYM_OK) { cagym_destroy(e); return rc; }
+    A(dalloc(e, &d6, SM * 6)); A(dalloc(e, &e->sc_heading_buf, SM)); A(dalloc(e, &dcoop, SM));
+    A(dalloc(e, &dpol, SM)); A(dalloc(e, &ddyn, SM)); A(dalloc(e, &dna, S)); A(dalloc(e, &dno, S));
+    if (cfg->max_obstacles > 0) {
+        A(dalloc(e, &dmap, S * CAGYM_MAPD * CAGYM_MAPW));
+        A(dalloc(e, &e->sc_obst, S * (size_t)cfg->max_obstacles * 4));
+    }
+    D.sc_agents6 = d6; D.sc_heading0 = nullptr; D.sc_coop = dcoop; D.sc_policy = dpol; D.sc_dyn = ddyn;
+    D.sc_nagents = dna; D.sc_nobst = dno; D.map_bits = dmap;
+    A(dalloc(e, &D.px, NM)); A(dalloc(e, &D.py, NM)); A(dalloc(e, &D.vx, NM)); A(dalloc(e, &D.vy, NM));
+    A(dalloc(e, &D.heading, NM)); A(dalloc(e, &D.heading_ego, NM)); A(dalloc(e, &D.dist_goal, NM));
+    A(dalloc(e, &D.time_rem, NM)); A(dalloc(e, &D.t, NM)); A(dalloc(e, &D.gx, NM)); A(dalloc(e, &D.gy, NM));
+    A(dalloc(e, &D.radius, NM)); A(dalloc(e, &D.pref, NM)); A(dalloc(e, &D.speed, NM)); A(dalloc(e, &D.dhead, NM));
+    A(dalloc(e, &D.aux0, NM)); A(dalloc(e, &D.aux1, NM)); A(dalloc(e, &D.coop, NM));
+    A(dalloc(e, &D.action, NM * 2)); A(dalloc(e, &D.status, NM)); A(dalloc(e, &D.step_num, NM));
+    A(dalloc(e, &D.n_observed, NM));
+    A(dalloc(e, &D.n_agents, N)); A(dalloc(e, &D.episode, N)); A(dalloc(e, &D.ep_len, N));
+    A(dalloc(e, &D.ep_return, N)); A(dalloc(e, &D.stat_return, N)); A(dalloc(e, &D.stat_episodes, N));
+    A(dalloc(e, &D.stat_steps, N)); A(dalloc(e, &D.stat_outcomes, N * 3));
+#undef A
+    e->err.clear();
+    size_t lds = cagym_lds_bytes((int)M);
+    if (lds > 160 * 1024) { cagym_destroy(e); return fail(nullptr, CAGYM_E_UNSUPPORTED, "LDS budget exceeded"); }
+    // > 64 KiB of dynamic LDS needs the attribute raised
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_step), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_reset), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipGetLastError();
+    *env_out = e;
+    return CAGYM_OK;
+}
+
+int cagym_destroy(void* env) {
+    Env* e = reinterpret_cast<Env*>(env);
+    if (!e) return CAGYM_OK;
+    for (void* p : e->allocs)
+        if (p) (void)hipFree(p);
+    delete e;
+    return CAGYM_OK;
+}
+
+int cagym_set_scenarios(void* env, const double* agents6, const double* heading0, const int32_t* policy_id,
+                        const int32_t* dynamics_id, const int32_t* n_agents, const double* coop,
+                        const double* obstacles, const int32_t* n_obst, void* stream) {
+    Env* e = reinterpret_cast<Env*>(env);
+    if (!e) return fail(nullptr, CAGYM_E_INVALID, "null env");
+    if (!agents6 || !policy_id || !dynamics_id) return fail(e, CAGYM_E_INVALID, "agents6 / policy_id / dynamics_id are required");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    const size_t S = e->cfg.n_scenarios, M = e->cfg.max_agents, SM = S * M;
+    // validate ids on the host: the kernels index switch tables with them
+    for (size_t k = 0; k < SM; k++) {
+        if (policy_id[k] < 0 || policy_id[k] > CAGYM_POL_IGMCTS) return fail(e, CAGYM_E_INVALID, "policy id out of range");
+        if (dynamics_id[k] < 0 || dynamics_id[k] > CAGYM_DYN_FIRSTORDER) return fail(e, CAGYM_E_INVALID, "dynamics id out of range");
+    }
+    std::vector<int32_t> na(S), no(S, 0);
+    for (size_t s = 0; s < S; s++) {
+        na[s] = n_agents ? n_agents[s] : (int32_t)M;
+        if (na[s] < 0 || na[s] > (int32_t)M) return fail(e, CAGYM_E_INVALID, "n_agents out of range");
+        if (n_obst && e->cfg.max_obstacles > 0) {
+            no[s] = n_obst[s];
+            if (no[s] < 0 || no[s] > e->cfg.max_obstacles) return fail(e, CAGYM_E_INVALID, "n_obst out of range");
+        }
+    }
+    std::vector<double> cp(SM, 1.0);  // agent.py:10
+    if (coop) memcpy(cp.data(), coop, SM * sizeof(double));
+    CagymDev& D = e->D;
+    double* dh0 = e->sc_heading_buf;
+    HIPCHK(e, hipMemcpyAsync(const_cast<double*>(D.sc_agents6), agents6, SM * 6 * sizeof(double), hipMemcpyHostToDevice, st));
+    if (heading0) {
+        HIPCHK(e, hipMemcpyAsync(dh0, heading0, SM * sizeof(double), hipMemcpyHostToDevice, st));
+        D.sc_heading0 = dh0;
+    } else {
+        D.sc_heading0 = nullptr;
+    }
+    HIPCHK(e, hipMemcpyAsync(const_cast<int32_t*>(D.sc_policy), policy_id, SM * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    HIPCHK(e, hipMemcpyAsync(const_cast<int32_t*>(D.sc_dyn), dynamics_id, SM * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    HIPCHK(e, hipMemcpyAsync(const_cast<int32_t*>(D.sc_nagents), na.data(), S * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    HIPCHK(e, hipMemcpyAsync(const_cast<double*>(D.sc_coop), cp.data(), SM * sizeof(double), hipMemcpyHostToDevice, st));
+    HIPCHK(e, hipMemcpyAsync(const_cast<int32_t*>(D.sc_nobst), no.data(), S * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    if (e->cfg.max_obstacles > 0) {
+        if (obstacles)
+            HIPCHK(e, hipMemcpyAsync(e->sc_obst, obstacles, S * (size_t)e->cfg.max_obstacles * 4 * sizeof(double), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_rasterize, dim3((unsigned)S), dim3(256), 0, st, e->sc_obst, D.sc_nobst, e->cfg.max_obstacles,
+                           const_cast<uint32_t*>(D.map_bits));
+        HIPCHK(e, hipGetLastError());
+    }
+    // host staging vectors die at return: the copies above must have consumed them
+    HIPCHK(e, hipStreamSynchronize(st));
+    // a new pool restarts the episode numbering
+    HIPCHK(e, hipMemsetAsync(D.episode, 0, e->cfg.n_worlds * sizeof(int32_t), st));
+    e->scenarios_set = true;
+    return CAGYM_OK;
+}
+
+int cagym_reset(void* env, const uint8_t* world_mask, int advance_episode, const cagym_outputs* out, void* stream) {
+    Env* e = reinterpret_cast<Env*>(env);
+    if (!e) return fail(nullptr, CAGYM_E_INVALID, "null env");
+    if (!e->scenarios_set) return fail(e, CAGYM_E_STATE, "cagym_reset before cagym_set_scenarios");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    CagymOut o = to_out(out);
+    hipLaunchKernelGGL(k_reset, dim3(n_waves(e)), dim3(64), cagym_lds_bytes(e->cfg.max_agents), st, e->D, world_mask,
+                       advance_episode, o);
+    HIPCHK(e, hipGetLastError());
+    if (e->cfg.laserscan && o.laserscan) return cagym_laserscan(env, o.laserscan, stream);
+    return CAGYM_OK;
+}
+
+int cagym_step(void* env, const float* ext_actions, const cagym_outputs* out, void* stream) {
+    Env* e = reinterpret_cast<Env*>(env);
+    if (!e) return fail(nullptr, CAGYM_E_INVALID, "null env");
+    if (!e->scenarios_set) return fail(e, CAGYM_E_STATE, "cagym_step before cagym_set_scenarios");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    CagymOut o = to_out(out);
+    hipLaunchKernelGGL(k_step, dim3(n_waves(e)), dim3(64), cagym_lds_bytes(e->cfg.max_agents), st, e->D, ext_actions, o);
+    HIPCHK(e, hipGetLastError());
+    if (e->cfg.laserscan && o.laserscan) return cagym_laserscan(env, o.laserscan, stream);
+    return CAGYM_OK;
+}
+
+int cagym_rollout(void* env, int n_steps, int auto_reset, const cagym_outputs* out, void* stream) {
+    Env* e = reinterpret_cast<Env*>(env);
+    if (!e) return fail(nullptr, CAGYM_E_INVALID, "null env");
+    if (!e->scenarios_set) return fail(e, CAGYM_E_STATE, "cagym_rollout before cagym_set_scenarios");
+    if (n_steps < 1) return fail(e, CAGYM_E_INVALID, "n_steps must be >= 1");
+    if (e->cfg.laserscan && out && out->laserscan)
+        return fail(e, CAGYM_E_UNSUPPORTED, "cagym_rollout does not produce laserscan (use cagym_step)");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    CagymOut o = to_out(out);
+    size_t lds = cagym_lds_bytes(e->cfg.max_agents);
+    if (auto_reset)
+        hipLaunchKernelGGL(k_rollout<true>, dim3(n_waves(e)), dim3(64), lds, st, e->D, n_steps, o);
+    else
+        hipLaunchKernelGGL(k_rollout<false>, dim3(n_waves(e)), dim3(64), lds, st, e->D, n_steps, o);
+    HIPCHK(e, hipGetLastError());
+    return CAGYM_OK;
+}
+
+int cagym_laserscan(void* env, float* laserscan, void* stream) {
+    Env* e = reinterpret_cast<Env*>(env);
+    if (!e) return fail(nullptr, CAGYM_E_INVALID, "null env");
+    if (!laserscan) return fail(e, CAGYM_E_INVALID, "null laserscan buffer");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    size_t total = (size_t)e->cfg.n_worlds * e->cfg.max_agents * 16;
+    hipLaunchKernelGGL(k_laserscan, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, e->D, laserscan);
+    HIPCHK(e, hipGetLastError());
+    return CAGYM_OK;
+}
+
+int cagym_get_state(void* env, cagym_state_ptrs* out) {
+    Env* e = reinterpret_cast<Env*>(env);
+    if (!e || !out) return fail(e, CAGYM_E_INVALID, "null argument");
+    const CagymDev& D = e->D;
+    out->pos_x = D.px; out->pos_y = D.py; out->vel_x = D.vx; out->vel_y = D.vy; out->heading = D.heading;
+    out->heading_ego = D.heading_ego; out->dist_to_goal = D.dist_goal; out->time_remaining = D.time_rem; out->t = D.t;
+    out->goal_x = D.gx; out->goal_y = D.gy; out->radius = D.radius; out->pref_speed = D.pref; out->speed = D.speed;
+    out->delta_heading = D.dhead; out->aux0 = D.aux0; out->aux1 = D.aux1;
+    out->action = D.action; out->status = D.status; out->step_num = D.step_num; out->n_agents = D.n_agents;
+    out->n_observed = D.n_observed; out->episode = D.episode; out->map_bits = const_cast<uint32_t*>(D.map_bits);
+    out->stat_return = D.stat_return; out->stat_episodes = D.stat_episodes; out->stat_steps = D.stat_steps;
+    out->stat_outcomes = D.stat_outcomes;
+    return CAGYM_OK;
+}
+
+}  // extern "C"

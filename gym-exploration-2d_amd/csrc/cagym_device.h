@@ -1,0 +1,271 @@
+// cagym_device.h -- device-side state layout and per-agent arithmetic (gfx950 / CDNA4).
+//
+// One lane = one agent slot; a world (M slots) never straddles a wavefront, so all
+// agent<->agent exchange is wave-local: an LDS neighbour tile written and read by the same
+// wave (LDS ops of one wave execute in issue order) plus 64-bit ballots for per-world
+// reductions.  No MFMA: there is no dense contraction on this path.
+//
+// Arithmetic follows the reference exactly where it defines masks: pos/heading/time in fp64
+// (agent.py:21-25), actions through fp32 (env.py:289), np.dot / np.linalg.norm as
+// fma(a1,b1,a0*b0) (see oracle/cagym_oracle.c dot2), everything else un-contracted
+// (-ffp-contract=off).  Reference citations: env.py = envs/collision_avoidance_env.py.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/cagym.h"
+
+#define CAGYM_WAVE 64
+#define CAGYM_MAPD 300
+#define CAGYM_MAPW 10 /* u32 words per raster row (320 bits) */
+#define CAGYM_MAXNB 10 /* RVO maxNeighbors (policies/RVOPolicy.py:14) */
+
+static constexpr double kPi = 3.141592653589793;
+
+// Everything the kernels need, passed by value (device pointers + scalars).
+struct CagymDev {
+    int N, M, S, Kobs, go_mode, collide_static, laserscan;
+    double dt;
+    // scenario pool [S, ...]
+    const double* sc_agents6;
+    const double* sc_heading0;  // may be null
+    const int32_t* sc_policy;
+    const int32_t* sc_dyn;
+    const int32_t* sc_nagents;
+    const double* sc_coop;
+    const int32_t* sc_nobst;
+    const uint32_t* map_bits;  // [S,300,10] or null
+    // state [N*M]
+    double *px, *py, *vx, *vy, *heading, *heading_ego, *dist_goal, *time_rem, *t;
+    double *gx, *gy, *radius, *pref, *speed, *dhead, *aux0, *aux1, *coop;
+    float* action;
+    uint32_t* status;
+    int32_t *step_num, *n_observed;
+    // per world [N]
+    int32_t *n_agents, *episode, *ep_len;
+    float* ep_return;
+    float* stat_return;
+    int32_t *stat_episodes, *stat_steps, *stat_outcomes;
+};
+
+struct CagymOut {
+    float* obs_oas;
+    float* obs_ego;
+    float* laserscan;
+    float* reward;
+    uint8_t* flags;
+    uint8_t* game_over;
+};
+
+// Per-lane agent record held in registers across a step (and across steps in the rollout).
+struct Agent {
+    double px, py, vx, vy, h, he, dg, trem, t, gx, gy, r, pref, speed, dh, aux0, aux1, coop;
+    float a0, a1;
+    uint32_t st;  // CAGYM_FLAG_* | policy << 8 | dyn << 12
+    int step;
+};
+
+#define ST_POLICY(st) (((st) >> 8) & 15u)
+#define ST_DYN(st) (((st) >> 12) & 15u)
+
+__device__ __forceinline__ double dot2(double a0, double a1, double b0, double b1) { return fma(a1, b1, a0 * b0); }
+__device__ __forceinline__ double norm2(double x, double y) { return sqrt(dot2(x, y, x, y)); }
+__device__ __forceinline__ double clipd(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+// util.py:27-32.  Non-finite / absurd inputs (outside any action space) take a closed form so a
+// wave can never spin: every loop in this file has an exit every lane reaches.
+__device__ __forceinline__ double wrap_angle(double a) {
+    if (!(fabs(a) <= 64.0 * kPi)) {
+        if (!isfinite(a)) return a;
+        a = a - 2 * kPi * floor((a + kPi) / (2 * kPi));
+    }
+    while (a >= kPi) a -= 2 * kPi;
+    while (a < -kPi) a += 2 * kPi;
+    return a;
+}
+
+// Dynamics.update_ego_frame (dynamics/Dynamics.py:14-28) + Agent.get_ref (agent.py:250-269).
+// Returns ref_prll in (prx, pry).
+__device__ __forceinline__ void update_ego_frame(Agent& A, double& prx, double& pry) {
+    double gx = A.gx - A.px, gy = A.gy - A.py;
+    double dist = sqrt(gx * gx + gy * gy);
+    A.dg = dist;
+    prx = gx;
+    pry = gy;
+    if (dist > 1e-8) {
+        prx = gx / dist;
+        pry = gy / dist;
+    }
+    double ang = atan2(pry, prx);
+    A.he = wrap_angle(A.h - ang);
+}
+
+__device__ __forceinline__ void ref_axes(const Agent& A, double& prx, double& pry) {
+    double gx = A.gx - A.px, gy = A.gy - A.py;
+    double dist = sqrt(gx * gx + gy * gy);
+    prx = gx;
+    pry = gy;
+    if (dist > 1e-8) {
+        prx = gx / dist;
+        pry = gy / dist;
+    }
+}
+
+// Agent.__init__ (agent.py:9-109) from scenario row `s` (index into the [S*M] pool).
+__device__ __forceinline__ void init_agent(const CagymDev& D, Agent& A, int sidx, int slot, bool active) {
+    const double* s6 = D.sc_agents6 + ((size_t)sidx * D.M + slot) * 6;
+    A.px = s6[0];
+    A.py = s6[1];
+    A.gx = s6[2];
+    A.gy = s6[3];
+    A.pref = s6[4];
+    A.r = s6[5];
+    A.vx = A.vy = 0.0;
+    A.speed = 0.0;
+    A.dh = 0.0;
+    A.aux0 = A.aux1 = 0.0;
+    A.a0 = A.a1 = 0.f;
+    size_t k = (size_t)sidx * D.M + slot;
+    A.h = D.sc_heading0 ? D.sc_heading0[k] : atan2(A.gy - A.py, A.gx - A.px);
+    A.coop = D.sc_coop[k];
+    A.trem = 3.0 * ((norm2(A.px - A.gx, A.py - A.gy) - 0.75) / A.pref);  // agent.py:59-63
+    A.t = 0.0;
+    A.step = 0;
+    A.st = ((uint32_t)D.sc_policy[k] << 8) | ((uint32_t)D.sc_dyn[k] << 12) | (active ? CAGYM_FLAG_ACTIVE : 0u);
+    double prx, pry;
+    update_ego_frame(A, prx, pry);
+}
+
+__device__ __forceinline__ void load_agent(const CagymDev& D, Agent& A, size_t a) {
+    A.px = D.px[a]; A.py = D.py[a]; A.vx = D.vx[a]; A.vy = D.vy[a];
+    A.h = D.heading[a]; A.he = D.heading_ego[a]; A.dg = D.dist_goal[a];
+    A.trem = D.time_rem[a]; A.t = D.t[a]; A.gx = D.gx[a]; A.gy = D.gy[a];
+    A.r = D.radius[a]; A.pref = D.pref[a]; A.speed = D.speed[a]; A.dh = D.dhead[a];
+    A.aux0 = D.aux0[a]; A.aux1 = D.aux1[a]; A.coop = D.coop[a];
+    A.a0 = D.action[2 * a]; A.a1 = D.action[2 * a + 1];
+    A.st = D.status[a]; A.step = D.step_num[a];
+}
+
+__device__ __forceinline__ void store_agent(const CagymDev& D, const Agent& A, size_t a, bool constants) {
+    D.px[a] = A.px; D.py[a] = A.py; D.vx[a] = A.vx; D.vy[a] = A.vy;
+    D.heading[a] = A.h; D.heading_ego[a] = A.he; D.dist_goal[a] = A.dg;
+    D.time_rem[a] = A.trem; D.t[a] = A.t; D.speed[a] = A.speed; D.dhead[a] = A.dh;
+    D.aux0[a] = A.aux0; D.aux1[a] = A.aux1;
+    reinterpret_cast<float2*>(D.action)[a] = make_float2(A.a0, A.a1);
+    D.status[a] = A.st; D.step_num[a] = A.step;
+    if (constants) {
+        D.gx[a] = A.gx; D.gy[a] = A.gy; D.radius[a] = A.r; D.pref[a] = A.pref; D.coop[a] = A.coop;
+    }
+}
+
+// CARRLPolicy table (policies/CARRLPolicy.py:5-15): np.linspace(-pi/6, pi/6, 11)
+__device__ __forceinline__ double carrl_heading(int k) {
+    double lo = -(kPi / 6), hi = kPi / 6;
+    double step = (hi - lo) / 10.0;
+    if (k >= 10) return hi;
+    if (k < 0) k = 0;
+    return (double)k * step + lo;
+}
+
+// Agent.take_action (agent.py:147-190) + dynamics/*.py.  `act` is the fp32 pair of env.py:289.
+__device__ __forceinline__ void take_action(Agent& A, float act0, float act1, double dt) {
+    if (A.st & (CAGYM_FLAG_AT_GOAL | CAGYM_FLAG_RAN_OUT_OF_TIME | CAGYM_FLAG_IN_COLLISION)) {  // agent.py:148-159
+        if (A.st & CAGYM_FLAG_AT_GOAL) A.st |= CAGYM_FLAG_WAS_AT_GOAL;
+        if (A.st & CAGYM_FLAG_IN_COLLISION) A.st |= CAGYM_FLAG_WAS_IN_COLLISION;
+        if (!(A.st & CAGYM_FLAG_AT_GOAL)) A.t += dt;
+        A.vx = A.vy = 0.0;
+        return;
+    }
+    A.a0 = act0;
+    A.a1 = act1;
+    double a0 = (double)act0, a1 = (double)act1;
+    double h = A.h, speed, hn;
+    switch (ST_DYN(A.st)) {
+        default:
+        case CAGYM_DYN_UNICYCLE:
+            speed = a0;
+            hn = wrap_angle(a1 + h);
+            break;
+        case CAGYM_DYN_MAXTURNRATE: {
+            double tr = clipd(a1 / dt, -3.0, 3.0);
+            speed = a0;
+            hn = wrap_angle(tr * dt + h);
+            break;
+        }
+        case CAGYM_DYN_MAXACC: {  // aux0 = current_speed, aux1 = current_turning_rate
+            double tr = clipd(a1 / dt, -3.0, 3.0);
+            double lacc = clipd(2.0 * (a0 - A.aux0), -2.0, 2.0);
+            double tacc = clipd(2.0 * (tr - A.aux1), -3.0, 3.0);
+            A.aux0 += lacc * dt;
+            A.aux0 = clipd(A.aux0, -1.1, 1.1);
+            A.aux1 += tacc * dt;
+            speed = A.aux0;
+            hn = wrap_angle(A.aux1 * dt + h);
+            break;
+        }
+        case CAGYM_DYN_SECONDORDER: {  // aux0 = angular_speed_global_frame
+            speed = clipd(norm2(A.vx, A.vy) + a0 * dt, 0.0, 1.0);
+            double tr = A.aux0 + a1 * dt;
+            A.aux0 = clipd(tr, -3.0, 3.0);
+            hn = wrap_angle(A.aux0 * dt + h);
+            break;
+        }
+        case CAGYM_DYN_FIRSTORDER:
+            speed = a0;
+            hn = wrap_angle(a1 * dt + h);
+            break;
+    }
+    double s, c;
+    sincos(hn, &s, &c);
+    double dx = speed * c * dt, dy = speed * s * dt;
+    A.px += dx;
+    A.py += dy;
+    A.vx = speed * c;
+    A.vy = speed * s;
+    A.speed = speed;
+    A.dh = wrap_angle(hn - h);
+    A.h = hn;
+    double prx, pry;
+    update_ego_frame(A, prx, pry);
+    double ex = A.px - A.gx, ey = A.py - A.gy;
+    if (ex * ex + ey * ey <= 0.75 * 0.75) A.st |= CAGYM_FLAG_AT_GOAL;  // utils/end_conditions.py:3-6
+    else A.st &= ~(uint32_t)CAGYM_FLAG_AT_GOAL;
+    A.trem -= dt;  // agent.py:184-188
+    A.t += dt;
+    A.step += 1;
+    if (A.trem <= 0.0) A.st |= CAGYM_FLAG_RAN_OUT_OF_TIME;
+}
+
+// Map.world_coordinates_to_map_indices (Map.py:40-47)
+__device__ __forceinline__ bool world_to_cell(double x, double y, int& gx, int& gy) {
+    const double cell = 0.1, ox = (30 / 2.) / cell;
+    double fx = floor(ox - y / cell), fy = floor(ox + x / cell);
+    // clamp before the int conversion (out-of-range doubles): far outside the map either way
+    fx = fx < -1e6 ? -1e6 : (fx > 1e6 ? 1e6 : fx);
+    fy = fy < -1e6 ? -1e6 : (fy > 1e6 ? 1e6 : fy);
+    gx = (int)fx;
+    gy = (int)fy;
+    return gx >= 0 && gy >= 0 && gx < CAGYM_MAPD && gy < CAGYM_MAPD;
+}
+
+__device__ __forceinline__ bool map_bit(const uint32_t* map, int gx, int gy) {
+    return (map[gx * CAGYM_MAPW + (gy >> 5)] >> (gy & 31)) & 1u;
+}
+
+// wall test of _check_for_collisions (env.py:656-666) with the disk mask of Map.py:67-71
+__device__ __forceinline__ bool wall_collision(const uint32_t* map, double px, double py, double radius) {
+    int pi, pj;
+    if (!world_to_cell(px, py, pi, pj)) return false;
+    double rr = radius / 0.1, r2 = rr * rr;
+    int R = (int)ceil(rr) + 1;
+    if (R > 64) R = 64;
+    for (int y = pi - R; y <= pi + R; y++) {
+        if (y < 0 || y >= CAGYM_MAPD) continue;
+        double dy = (double)(y - pi);
+        for (int x = pj - R; x <= pj + R; x++) {
+            if (x < 0 || x >= CAGYM_MAPD) continue;
+            double dx = (double)(x - pj);
+            if (dx * dx + dy * dy < r2 && map_bit(map, y, x)) return true;
+        }
+    }
+    return false;
+}

@@ -1,0 +1,146 @@
+/* cagym.h -- C ABI of the MI355X-native batched CollisionAvoidanceEnv (libcagym_hip.so).
+ *
+ * The reference (mlodel/gym-exploration-2d) has no FFI layer: its boundary is the Python
+ * gym.Env object `CollisionAvoidanceEnv` (gym_collision_avoidance/envs/collision_avoidance_env.py,
+ * "env.py" below).  Each entry point here cites the reference interface it replaces; the Python
+ * host (gym-exploration-2d_amd/) binds them with ctypes and mirrors the gym.Env surface.
+ *
+ * Conventions
+ *  - Plain pointers and sizes only.  Pointers marked DEVICE are HIP device pointers (e.g.
+ *    torch.Tensor.data_ptr() of a contiguous ROCm tensor); HOST pointers are ordinary memory.
+ *  - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ *    all work is enqueued on it, nothing inside cagym_step / cagym_rollout synchronises the host.
+ *  - Every call returns 0 or a negative CAGYM_E* code; cagym_last_error() gives the message.
+ *    Nothing throws across the ABI.  There is NO CPU fallback: without a HIP device
+ *    cagym_create fails with CAGYM_E_NODEVICE.
+ *  - A handle is not thread-safe; one handle per GPU.
+ *  - Layout: N worlds x M agent slots, structure-of-arrays, world-major ([N][M]).
+ */
+#ifndef CAGYM_H
+#define CAGYM_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CAGYM_VERSION 100 /* 0.1.0 */
+
+enum { CAGYM_OK = 0, CAGYM_E_INVALID = -1, CAGYM_E_NODEVICE = -2, CAGYM_E_HIP = -3, CAGYM_E_NOMEM = -4,
+       CAGYM_E_STATE = -5, CAGYM_E_UNSUPPORTED = -6 };
+
+/* policy ids: which action map / policy drives an agent (env.py:298-320) */
+enum { CAGYM_POL_STATIC = 0,   /* policies/StaticPolicy.py:9-12            a = (0, 0)                      */
+       CAGYM_POL_NONCOOP = 1,  /* policies/NonCooperativePolicy.py:10-13   a = (pref_speed, -heading_ego)  */
+       CAGYM_POL_EXTERNAL = 2, /* raw (speed, delta_heading) from ext_actions                  */
+       CAGYM_POL_LEARNING = 3, /* policies/LearningPolicy.py:11-16         a = (v_pref*u0, 4*(2*u1-1))     */
+       CAGYM_POL_CARRL = 4,    /* policies/CARRLPolicy.py:5-15             11-row table, index in ext[.,0] */
+       CAGYM_POL_RVO = 5,      /* policies/RVOPolicy.py:53-117             ORCA half-planes + 2-D LP       */
+       CAGYM_POL_GA3C = 6,     /* policies/GA3CCADRLPolicy.py:34-43        action supplied by cagym_ga3c_* */
+       CAGYM_POL_IGMCTS = 7 }; /* policies/ig_mcts.py:79-109               (v, omega) supplied by planner  */
+
+/* dynamics ids (envs/dynamics/) */
+enum { CAGYM_DYN_UNICYCLE = 0,    /* UnicycleDynamics.py:10-24                 */
+       CAGYM_DYN_MAXTURNRATE = 1, /* UnicycleDynamicsMaxTurnRate.py:11-25      */
+       CAGYM_DYN_MAXACC = 2,      /* UnicycleDynamicsMaxAcc.py:17-39           */
+       CAGYM_DYN_SECONDORDER = 3, /* UnicycleSecondOrderEulerDynamics.py:12-29 */
+       CAGYM_DYN_FIRSTORDER = 4 };/* FirstOrderDynamics.py:10-23               */
+
+/* game_over rule (env.py:722-736) */
+enum { CAGYM_GO_AGENT0 = 0,    /* EVALUATE_MODE && !HOMOGENEOUS_TESTING, or TRAIN_SINGLE_AGENT */
+       CAGYM_GO_ALL = 1,       /* EVALUATE_MODE && HOMOGENEOUS_TESTING                         */
+       CAGYM_GO_LEARNING = 2 };/* all agents with CAGYM_POL_LEARNING done                      */
+
+/* per-agent status byte (`flags` output and state view) */
+enum { CAGYM_FLAG_AT_GOAL = 1, CAGYM_FLAG_IN_COLLISION = 2, CAGYM_FLAG_RAN_OUT_OF_TIME = 4, CAGYM_FLAG_DONE = 8,
+       CAGYM_FLAG_WAS_AT_GOAL = 16, CAGYM_FLAG_WAS_IN_COLLISION = 32, CAGYM_FLAG_ACTIVE = 64 };
+
+/* Replaces the class attributes of envs/config.py read by the hot path. */
+typedef struct {
+    int32_t n_worlds;            /* N: worlds stepped together (one reference env instance each)            */
+    int32_t max_agents;          /* M: Config.MAX_NUM_AGENTS_IN_ENVIRONMENT (config.py:70); 2..64           */
+    int32_t n_scenarios;         /* S >= N: scenario pool; world w starts episode e on scenario (w+e*N)%S   */
+    int32_t max_obstacles;       /* rectangles per scenario (0 = free space; env.py:492-497)                */
+    int32_t game_over_mode;      /* CAGYM_GO_*                                                              */
+    int32_t collide_with_static; /* Config.COLLISION_AV_W_STATIC_AGENT (config.py:52)                       */
+    int32_t laserscan;           /* 1: every agent carries a LaserScanSensor (sensors/LaserScanSensor.py)   */
+    int32_t device;              /* HIP device ordinal                                                      */
+    double dt;                   /* Config.DT (config.py:29)                                                */
+} cagym_config;
+
+#define CAGYM_EGO_WIDTH 12
+/* Caller-owned DEVICE output buffers of one step.  Any pointer may be NULL (not written).
+ * obs_ego columns: dist_to_goal, rel_goal.x, rel_goal.y, radius, heading_ego_frame,
+ *   heading_global_frame, pos.x, pos.y, pref_speed, num_other_agents_observed, use_ppo, 0
+ *   (the scalar keys of Config.STATE_INFO_DICT, config.py:104-215).
+ * obs_oas: OtherAgentsStatesSensor table, rows farthest->closest (sensors/OtherAgentsStatesSensor.py:11-77).
+ * For cagym_rollout every buffer has a leading [T] dimension. */
+typedef struct {
+    float* obs_oas;     /* [N, M, M-1, 10] f32 */
+    float* obs_ego;     /* [N, M, 12]      f32 */
+    float* laserscan;   /* [N, M, 16]      f32 (only when cfg.laserscan)                           */
+    float* reward;      /* [N, M]          f32: _compute_rewards (env.py:502-567), all agents      */
+    uint8_t* flags;     /* [N, M]          u8 : CAGYM_FLAG_* after the step (env.py:711-721)       */
+    uint8_t* game_over; /* [N]             u8 : env.py:722-738                                     */
+} cagym_outputs;
+
+/* Zero-copy DEVICE views of the SoA state (for parity tests / Agent-like host views; agent.py:9-109). */
+typedef struct {
+    double *pos_x, *pos_y, *vel_x, *vel_y, *heading, *heading_ego, *dist_to_goal, *time_remaining, *t;
+    double *goal_x, *goal_y, *radius, *pref_speed, *speed, *delta_heading, *aux0, *aux1;
+    float* action;          /* [N, M, 2] last applied (speed, delta_heading), fp32 as env.py:289 */
+    uint32_t* status;       /* [N, M] bits 0-7 CAGYM_FLAG_*, 8-11 policy id, 12-15 dynamics id   */
+    int32_t* step_num;      /* [N, M] agent.py:186                                               */
+    int32_t* n_agents;      /* [N]                                                               */
+    int32_t* n_observed;    /* [N, M] num_other_agents_observed                                  */
+    int32_t* episode;       /* [N] episodes started by this world (selects the scenario)         */
+    uint32_t* map_bits;     /* [S, 300, 10] bit-packed occupancy rasters (Map.py:107-123) or NULL */
+    /* cumulative per-world episode statistics (the payload of the multi-GPU all-gather) */
+    float* stat_return;     /* [N] sum over finished episodes of agent-0 episode return          */
+    int32_t* stat_episodes; /* [N] finished episodes                                             */
+    int32_t* stat_steps;    /* [N] env steps in finished episodes                                */
+    int32_t* stat_outcomes; /* [N, 3] agents finished at goal / in collision / timed out         */
+} cagym_state_ptrs;
+
+int cagym_version(void);
+
+/* CollisionAvoidanceEnv.__init__ (env.py:60-160) for N worlds. */
+int cagym_create(const cagym_config* cfg, void** env_out);
+/* CollisionAvoidanceEnv.close (env.py:268-270). */
+int cagym_destroy(void* env);
+const char* cagym_last_error(void* env);
+
+/* set_agents / _init_agents / set_static_map (env.py:387-388, 403-476, 478-500): upload the scenario
+ * pool.  All pointers HOST.  agents6[S,M,6] = start_x, start_y, goal_x, goal_y, pref_speed, radius (the
+ * "legacy cadrl" row of test_cases.py:1970-2014); heading0[S,M] or NULL (toward goal, agent.py:29-31);
+ * policy_id / dynamics_id [S,M]; n_agents[S] or NULL (= M); coop[S,M] or NULL (1.0, agent.py:10);
+ * obstacles[S,K,4] = xl, yl, xu, yu or NULL; n_obst[S].  Rasterises the obstacle maps on device. */
+int cagym_set_scenarios(void* env, const double* agents6, const double* heading0, const int32_t* policy_id,
+                        const int32_t* dynamics_id, const int32_t* n_agents, const double* coop,
+                        const double* obstacles, const int32_t* n_obst, void* stream);
+
+/* reset() (env.py:234-266) for the worlds whose world_mask byte is non-zero (DEVICE [N], NULL = all):
+ * re-initialise agents from the world's current scenario, sense, write observations to `out`.
+ * advance_episode != 0 moves the masked worlds to their next scenario first. */
+int cagym_reset(void* env, const uint8_t* world_mask, int advance_episode, const cagym_outputs* out, void* stream);
+
+/* step(actions) (env.py:162-232): _take_action -> _compute_rewards(+_check_for_collisions) -> _get_obs ->
+ * _check_which_agents_done.  ext_actions DEVICE [N,M,2] f32 or NULL (all agents internal, env_utils.py:46). */
+int cagym_step(void* env, const float* ext_actions, const cagym_outputs* out, void* stream);
+
+/* n_steps consecutive step() calls in ONE launch for worlds whose agents are all driven internally
+ * (Static / NonCooperative / RVO): state stays in registers, every step writes its outputs to slice
+ * t of `out` ([T, ...] buffers; T = n_steps).  auto_reset != 0: a world whose game_over fires is
+ * reset onto its next scenario inside the kernel (what stable-baselines' DummyVecEnv does around the
+ * reference env, exp/env_utils.py:29-31) and its episode statistics are accumulated. */
+int cagym_rollout(void* env, int n_steps, int auto_reset, const cagym_outputs* out, void* stream);
+
+int cagym_get_state(void* env, cagym_state_ptrs* out);
+
+/* LaserScanSensor.sense (sensors/LaserScanSensor.py:27-58) on the current state -> laserscan [N,M,16]. */
+int cagym_laserscan(void* env, float* laserscan, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

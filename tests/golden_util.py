@@ -75,7 +75,8 @@ def canon_oas(oas, n_obs, tie=1e-9):
     return out, ties
 
 
-def replay(case, make_env, ftol=1e-12, oas_tol=1e-12, laser_tol=1e-12, check=None):
+def replay(case, make_env, ftol=1e-12, oas_tol=1e-12, laser_tol=1e-12, check=None, float_keys=None,
+           tie=1e-9, reward_tol=None):
     """Step a 1-world backend through the case; returns dict of max abs errors.
     Masks / integer fields must match exactly (assert)."""
     a6 = case["agents6"]
@@ -133,7 +134,7 @@ def replay(case, make_env, ftol=1e-12, oas_tol=1e-12, laser_tol=1e-12, check=Non
         return False
 
     def cmp(t):
-        for k in FLOAT_KEYS:
+        for k in (float_keys or FLOAT_KEYS):
             got = np.asarray(env.f(k))[0, :M]
             exp = case[k][t]
             if k == "past_actions":
@@ -145,7 +146,8 @@ def replay(case, make_env, ftol=1e-12, oas_tol=1e-12, laser_tol=1e-12, check=Non
                     got = np.where(kn, exp, got)
             e = np.abs(got.reshape(exp.shape) - exp).max() if exp.size else 0.0
             errs[k] = max(errs.get(k, 0.0), float(e))
-            assert e <= ftol * max(1.0, np.abs(exp).max()), (k, t, e, got, exp)
+            tol = reward_tol if (k == "reward" and reward_tol is not None) else ftol
+            assert e <= tol * max(1.0, np.abs(exp).max()), (k, t, e, got, exp)
         for k in MASK_KEYS:
             got = np.asarray(env.u(k))[0, :M].astype(bool)
             assert (got == case[k][t]).all(), (k, t, got, case[k][t])
@@ -153,8 +155,8 @@ def replay(case, make_env, ftol=1e-12, oas_tol=1e-12, laser_tol=1e-12, check=Non
         assert (np.asarray(env.i("step_num"))[0, :M] == case["step_num"][t]).all(), ("step_num", t)
         assert (np.asarray(env.i("num_other_agents_observed"))[0, :M] == case["num_other_agents_observed"][t]).all()
         nobs = case["num_other_agents_observed"][t]
-        got, _ = canon_oas(np.asarray(env.f("oas"))[0, :M], nobs)
-        exp, nt = canon_oas(case["oas"][t], nobs)
+        got, _ = canon_oas(np.asarray(env.f("oas"))[0, :M], nobs, tie)
+        exp, nt = canon_oas(case["oas"][t], nobs, tie)
         errs["oas_tie_groups"] = errs.get("oas_tie_groups", 0) + nt
         e = np.abs(got - exp).max()
         errs["oas"] = max(errs.get("oas", 0.0), float(e))
