@@ -168,6 +168,8 @@ __device__ __forceinline__ double carrl_heading(int k) {
 
 // Agent.take_action (agent.py:147-190) + dynamics/*.py.  `act` is the fp32 pair of env.py:289.
 __device__ __forceinline__ void take_action(Agent& A, float act0, float act1, double dt) {
+    A.a0 = act0;  // all_actions row (env.py:289): zeros for an agent that is already done
+    A.a1 = act1;
     if (A.st & (CAGYM_FLAG_AT_GOAL | CAGYM_FLAG_RAN_OUT_OF_TIME | CAGYM_FLAG_IN_COLLISION)) {  // agent.py:148-159
         if (A.st & CAGYM_FLAG_AT_GOAL) A.st |= CAGYM_FLAG_WAS_AT_GOAL;
         if (A.st & CAGYM_FLAG_IN_COLLISION) A.st |= CAGYM_FLAG_WAS_IN_COLLISION;
@@ -175,8 +177,6 @@ __device__ __forceinline__ void take_action(Agent& A, float act0, float act1, do
         A.vx = A.vy = 0.0;
         return;
     }
-    A.a0 = act0;
-    A.a1 = act1;
     double a0 = (double)act0, a1 = (double)act1;
     double h = A.h, speed, hn;
     switch (ST_DYN(A.st)) {

@@ -12,6 +12,7 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 FLOAT_KEYS = ["pos", "vel", "heading", "speed", "delta_heading", "dist_to_goal", "past_dist_to_goal",
               "heading_ego", "vel_ego", "ref_prll", "rel_goal", "time_remaining", "t", "past_actions", "reward"]
+ANGLE_KEYS = ("heading", "heading_ego", "delta_heading")
 MASK_KEYS = ["is_at_goal", "was_at_goal_already", "in_collision", "was_in_collision_already",
              "ran_out_of_time", "is_done"]
 
@@ -144,7 +145,10 @@ def replay(case, make_env, ftol=1e-12, oas_tol=1e-12, laser_tol=1e-12, check=Non
                 if kn.any():
                     errs["reward_knife_edges"] = errs.get("reward_knife_edges", 0) + int(kn.sum())
                     got = np.where(kn, exp, got)
-            e = np.abs(got.reshape(exp.shape) - exp).max() if exp.size else 0.0
+            diff = got.reshape(exp.shape) - exp
+            if k in ANGLE_KEYS:  # +pi and -pi are the same heading: util.wrap's branch there is ulp-dependent
+                diff = (diff + np.pi) % (2 * np.pi) - np.pi
+            e = np.abs(diff).max() if exp.size else 0.0
             errs[k] = max(errs.get(k, 0.0), float(e))
             tol = reward_tol if (k == "reward" and reward_tol is not None) else ftol
             assert e <= tol * max(1.0, np.abs(exp).max()), (k, t, e, got, exp)
