@@ -9,6 +9,7 @@
 
 #include "../../include/cagym.h"
 #include "cagym_kernels.h"
+#include "cagym_ig.h"
 
 namespace {
 
@@ -22,6 +23,9 @@ struct Env {
     bool scenarios_set = false;
     double* sc_obst = nullptr;
     double* sc_heading_buf = nullptr;
+    IgDev G{};
+    uint32_t* ig_any = nullptr;
+    bool ig_ready = false;
 };
 
 int fail(Env* e, int code, const std::string& msg) {
@@ -266,6 +270,131 @@ int cagym_get_state(void* env, cagym_state_ptrs* out) {
     out->n_observed = D.n_observed; out->episode = D.episode; out->map_bits = const_cast<uint32_t*>(D.map_bits);
     out->stat_return = D.stat_return; out->stat_episodes = D.stat_episodes; out->stat_steps = D.stat_steps;
     out->stat_outcomes = D.stat_outcomes;
+    return CAGYM_OK;
+}
+
+// ---- information-gain primitives -----------------------------------------------------------------
+static int ig_check(Env* e, const char* what) {
+    if (!e) return fail(nullptr, CAGYM_E_INVALID, "null env");
+    if (!e->ig_ready) return fail(e, CAGYM_E_STATE, std::string(what) + " before cagym_ig_init");
+    return CAGYM_OK;
+}
+
+int cagym_ig_init(void* env, void* stream) {
+    Env* e = reinterpret_cast<Env*>(env);
+    if (!e) return fail(nullptr, CAGYM_E_INVALID, "null env");
+    if (!e->scenarios_set) return fail(e, CAGYM_E_STATE, "cagym_ig_init before cagym_set_scenarios");
+    if (e->cfg.max_obstacles <= 0 || !e->D.map_bits)
+        return fail(e, CAGYM_E_UNSUPPORTED, "information-gain primitives need obstacle rasters (max_obstacles > 0)");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    const size_t S = e->cfg.n_scenarios, N = e->cfg.n_worlds;
+    if (!e->G.d2) {
+        int rc;
+        if ((rc = dalloc(e, &e->G.d2, S * CAGYM_MAPD * CAGYM_MAPD)) != CAGYM_OK) return rc;
+        if ((rc = dalloc(e, &e->G.belief, N * IG_BEL * IG_BEL)) != CAGYM_OK) return rc;
+        if ((rc = dalloc(e, &e->ig_any, S)) != CAGYM_OK) return rc;
+    }
+    e->G.N = (int)N; e->G.S = (int)S; e->G.map_bits = e->D.map_bits; e->G.sc_nobst = e->D.sc_nobst; e->G.episode = e->D.episode;
+    HIPCHK(e, hipMemsetAsync(e->ig_any, 0, S * sizeof(uint32_t), st));
+    hipLaunchKernelGGL(k_ig_edt_cols, dim3((unsigned)S), dim3(320), 0, st, e->G, e->ig_any);
+    hipLaunchKernelGGL(k_ig_edt_rows, dim3((unsigned)(S * CAGYM_MAPD)), dim3(320), 0, st, e->G, e->ig_any);
+    hipLaunchKernelGGL(k_ig_fill_belief, dim3((unsigned)N), dim3(256), 0, st, e->G, (const uint8_t*)nullptr);
+    HIPCHK(e, hipGetLastError());
+    e->ig_ready = true;
+    return CAGYM_OK;
+}
+
+int cagym_ig_reset_belief(void* env, const uint8_t* world_mask, void* stream) {
+    Env* e = reinterpret_cast<Env*>(env);
+    int rc = ig_check(e, "cagym_ig_reset_belief");
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_ig_fill_belief, dim3((unsigned)e->cfg.n_worlds), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), e->G, world_mask);
+    HIPCHK(e, hipGetLastError());
+    return CAGYM_OK;
+}
+
+int cagym_ig_get(void* env, uint32_t** edf_d2, double** belief) {
+    Env* e = reinterpret_cast<Env*>(env);
+    int rc = ig_check(e, "cagym_ig_get");
+    if (rc) return rc;
+    if (edf_d2) *edf_d2 = e->G.d2;
+    if (belief) *belief = e->G.belief;
+    return CAGYM_OK;
+}
+
+int cagym_ig_visible_cells(void* env, const double* poses, const int32_t* world, int Q, double fov_rad, double range,
+                           uint64_t* masks, void* stream) {
+    Env* e = reinterpret_cast<Env*>(env);
+    int rc = ig_check(e, "cagym_ig_visible_cells");
+    if (rc) return rc;
+    if (Q < 0 || !poses || !world || !masks) return fail(e, CAGYM_E_INVALID, "bad arguments");
+    if (Q == 0) return CAGYM_OK;
+    hipLaunchKernelGGL(k_ig_visible, dim3((unsigned)Q), dim3(128), 0, reinterpret_cast<hipStream_t>(stream), e->G, poses,
+                       world, fov_rad, range, reinterpret_cast<unsigned long long*>(masks));
+    HIPCHK(e, hipGetLastError());
+    return CAGYM_OK;
+}
+
+int cagym_ig_update_belief(void* env, const double* poses, const int32_t* n_poses, const double* detections,
+                           const int32_t* n_det, int P, int Dmax, double fov_rad, double range, uint64_t* observed,
+                           void* stream) {
+    Env* e = reinterpret_cast<Env*>(env);
+    int rc = ig_check(e, "cagym_ig_update_belief");
+    if (rc) return rc;
+    if (P < 1 || Dmax < 1 || !poses || !detections || !n_det) return fail(e, CAGYM_E_INVALID, "bad arguments");
+    hipLaunchKernelGGL(k_ig_update, dim3((unsigned)e->cfg.n_worlds), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       e->G, poses, n_poses, detections, n_det, P, Dmax, fov_rad, range,
+                       reinterpret_cast<unsigned long long*>(observed));
+    HIPCHK(e, hipGetLastError());
+    return CAGYM_OK;
+}
+
+int cagym_ig_mi_reward(void* env, const uint64_t* masks, const int32_t* world, int Q, double* reward, void* stream) {
+    Env* e = reinterpret_cast<Env*>(env);
+    int rc = ig_check(e, "cagym_ig_mi_reward");
+    if (rc) return rc;
+    if (Q < 0 || !masks || !world || !reward) return fail(e, CAGYM_E_INVALID, "bad arguments");
+    if (Q == 0) return CAGYM_OK;
+    hipLaunchKernelGGL(k_ig_reward, dim3((unsigned)Q), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), e->G,
+                       reinterpret_cast<const unsigned long long*>(masks), world, reward);
+    HIPCHK(e, hipGetLastError());
+    return CAGYM_OK;
+}
+
+int cagym_ig_next_pose(void* env, const double* poses, const double* actions, const int32_t* world,
+                       const double* radius, int Q, int xdt, double dt, double* next, uint8_t* feasible, void* stream) {
+    Env* e = reinterpret_cast<Env*>(env);
+    int rc = ig_check(e, "cagym_ig_next_pose");
+    if (rc) return rc;
+    if (Q < 0 || xdt < 1 || xdt > 1000 || !poses || !actions || !world || !radius || !next || !feasible)
+        return fail(e, CAGYM_E_INVALID, "bad arguments");
+    if (Q == 0) return CAGYM_OK;
+    hipLaunchKernelGGL(k_ig_next_pose, dim3((unsigned)((Q + 255) / 256)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), e->G, poses, actions, world, radius, Q, xdt, dt, next,
+                       feasible);
+    HIPCHK(e, hipGetLastError());
+    return CAGYM_OK;
+}
+
+int cagym_ig_rollouts(void* env, const double* pose0, const uint64_t* observed0, const uint64_t* exclude,
+                      const int32_t* world, const int32_t* n_steps, const double* radius, int Q, int nsims,
+                      int max_steps, int xdt, double dt, double fov_rad, double range, uint64_t seed, double* rewards,
+                      uint8_t* actions, double* final_pose, void* stream) {
+    Env* e = reinterpret_cast<Env*>(env);
+    int rc = ig_check(e, "cagym_ig_rollouts");
+    if (rc) return rc;
+    if (Q < 0 || nsims < 1 || max_steps < 0 || max_steps > 255 || xdt < 1 || xdt > 1000 || !pose0 || !observed0 ||
+        !exclude || !world || !n_steps || !radius || !rewards)
+        return fail(e, CAGYM_E_INVALID, "bad arguments");
+    if (Q == 0) return CAGYM_OK;
+    hipLaunchKernelGGL(k_ig_rollouts, dim3((unsigned)((size_t)Q * nsims)), dim3(128), 0,
+                       reinterpret_cast<hipStream_t>(stream), e->G, pose0,
+                       reinterpret_cast<const unsigned long long*>(observed0),
+                       reinterpret_cast<const unsigned long long*>(exclude), world, n_steps, radius, nsims, max_steps, xdt,
+                       dt, fov_rad, range, (unsigned long long)seed, rewards, actions, final_pose);
+    HIPCHK(e, hipGetLastError());
     return CAGYM_OK;
 }
 

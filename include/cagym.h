@@ -140,6 +140,42 @@ int cagym_get_state(void* env, cagym_state_ptrs* out);
 /* LaserScanSensor.sense (sensors/LaserScanSensor.py:27-58) on the current state -> laserscan [N,M,16]. */
 int cagym_laserscan(void* env, float* laserscan, void* stream);
 
+/* ---- information-gain planner primitives (cfg 5).  All pointers DEVICE.  A visibility set is a
+ * [60] u64 mask: bit i of word j <=> belief cell (i, j) (x index i, y index j; 0.5 m cells over 30x30 m). ---- */
+
+/* ig_mcts.set_param (policies/ig_mcts.py:56-77): build the Euclidean distance field of every scenario
+ * raster (edfMap.update, information_models/edfMap.py:11-12) and N belief grids at prior 1.0
+ * (targetMap.__init__, information_models/targetMap.py:7-24).  Needs max_obstacles > 0. */
+int cagym_ig_init(void* env, void* stream);
+/* re-initialise the belief grids of the masked worlds (NULL = all) to the prior. */
+int cagym_ig_reset_belief(void* env, const uint8_t* world_mask, void* stream);
+/* views: edf_d2 [S,300,300] u32 squared cell distances (EDF = sqrt(d2)*0.1), belief [N,60,60] f64 odds. */
+int cagym_ig_get(void* env, uint32_t** edf_d2, double** belief);
+/* targetMap.getVisibleCells (targetMap.py:43-84) for Q poses (x, y, phi) of worlds world[q]. */
+int cagym_ig_visible_cells(void* env, const double* poses, const int32_t* world, int Q, double fov_rad,
+                           double range, uint64_t* masks, void* stream);
+/* targetMap.update (targetMap.py:86-128), frame='global': poses [N,P,3] applied in order, n_poses [N] or
+ * NULL (= P), detections [N,P,Dmax,2] global positions, n_det [N,P]; observed [N,60] = union of the visible
+ * sets (NULL to skip).  ig_mcts.update_belief (ig_mcts.py:117-133). */
+int cagym_ig_update_belief(void* env, const double* poses, const int32_t* n_poses, const double* detections,
+                           const int32_t* n_det, int P, int Dmax, double fov_rad, double range, uint64_t* observed,
+                           void* stream);
+/* targetMap.get_reward_from_cells (targetMap.py:130-143): reward[q] = sum of cell MI over masks[q]. */
+int cagym_ig_mi_reward(void* env, const uint64_t* masks, const int32_t* world, int Q, double* reward, void* stream);
+/* ig_mcts.get_next_pose (ig_mcts.py:154-183): xdt Euler sub-steps of dt; feasible[q] = 0 where the
+ * reference returns None (next[q] is then the input pose). */
+int cagym_ig_next_pose(void* env, const double* poses, const double* actions, const int32_t* world,
+                       const double* radius, int Q, int xdt, double dt, double* next, uint8_t* feasible, void* stream);
+/* Tree._simulate (policies/pydecmcts/DecMCTS.py:233-271) x nsims per query: n_steps[q] uniformly random
+ * motion primitives (ig_mcts.mcts_avail_actions :247-253; counter-based RNG on (seed, q, sim, step)) from
+ * pose0[q] with already-observed set observed0[q]; reward = MI(observed minus exclude[q]) (mcts_reward :234-241).
+ * rewards [Q,nsims]; actions [Q,nsims,max_steps] primitive index 0..8 or 255 (infeasible draw; may be NULL);
+ * final_pose [Q,nsims,3] (may be NULL). */
+int cagym_ig_rollouts(void* env, const double* pose0, const uint64_t* observed0, const uint64_t* exclude,
+                      const int32_t* world, const int32_t* n_steps, const double* radius, int Q, int nsims,
+                      int max_steps, int xdt, double dt, double fov_rad, double range, uint64_t seed,
+                      double* rewards, uint8_t* actions, double* final_pose, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

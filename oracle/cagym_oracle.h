@@ -77,6 +77,27 @@ void cao_orca_action(int M, int ego, const double* pos, const double* vel, const
                      const double* pref_speed, const double* radius, double heading, double collab,
                      double dt, double* action_out);
 
+/* ---- information-gain primitives (cagym_oracle_ig.c); one world at a time ---- */
+/* edfMap.update (information_models/edfMap.py:11-12): edf[300*300] f64 and/or d2[300*300] u32 */
+void cao_edt(const uint8_t* map300, double* edf, uint32_t* d2);
+/* edfMap.checkVisibility (edfMap.py:21-47) */
+int cao_ig_check_visibility(const double* edf, const double* pose2, const double* goal2);
+/* targetMap.getVisibleCells (information_models/targetMap.py:43-84): mask[60] u64, bit i of mask[j] */
+int cao_ig_visible(const double* edf, const double* pose3, double fov_rad, double range, uint64_t* mask);
+/* targetMap.update (targetMap.py:86-128) */
+void cao_ig_update(double* belief, const double* edf, int P, const double* poses, const int32_t* ndet,
+                   const double* dets, int Dmax, double fov_rad, double range, uint64_t* observed);
+/* targetMap.get_reward_from_cells (targetMap.py:130-143) */
+double cao_ig_reward(const double* belief, const uint64_t* mask);
+/* ig_mcts.get_next_pose (policies/ig_mcts.py:154-183) */
+int cao_ig_next_pose(const double* edf, const double* pose3, const double* action2, int xdt, double dt, double radius,
+                     double* next3);
+uint32_t cao_ig_rand_primitive(uint64_t seed, uint32_t q, uint32_t sim, uint32_t step);
+/* Tree._simulate random roll-out (pydecmcts/DecMCTS.py:233-271) + mcts_reward (ig_mcts.py:234-241) */
+double cao_ig_rollout(const double* belief, const double* edf, const double* pose0, const uint64_t* observed0,
+                      const uint64_t* exclude, int n_steps, int xdt, double dt, double radius, double fov_rad,
+                      double range, uint64_t seed, uint32_t q, uint32_t sim, uint8_t* actions_out, double* pose_out);
+
 #ifdef __cplusplus
 }
 #endif

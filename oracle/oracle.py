@@ -55,6 +55,20 @@ def lib():
             getattr(L, n).argtypes = [C.c_void_p, C.c_int]
         L.cao_rasterize.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.cao_orca_action.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_double] * 3 + [C.c_void_p]
+        L.cao_edt.argtypes = [C.c_void_p] * 3
+        L.cao_ig_check_visibility.argtypes = [C.c_void_p] * 3
+        L.cao_ig_visible.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p]
+        L.cao_ig_update.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                    C.c_double, C.c_double, C.c_void_p]
+        L.cao_ig_reward.restype = C.c_double
+        L.cao_ig_reward.argtypes = [C.c_void_p, C.c_void_p]
+        L.cao_ig_next_pose.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_void_p]
+        L.cao_ig_rand_primitive.restype = C.c_uint32
+        L.cao_ig_rand_primitive.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]
+        L.cao_ig_rollout.restype = C.c_double
+        L.cao_ig_rollout.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
+                                                        C.c_double, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p,
+                                                        C.c_void_p]
         _lib = L
     return _lib
 
@@ -141,3 +155,63 @@ def orca_action(pos, vel, goal, pref_speed, radius, ego, heading, collab=0.5, dt
     lib().cao_orca_action(pos.shape[0], ego, _p(pos), _p(vel), _p(goal), _p(ps), _p(rd), float(heading),
                           float(collab), float(dt), _p(out))
     return out
+
+
+# ---- information-gain primitives (one world) --------------------------------------------------------
+FOV60 = 60.0 * np.pi / 180
+
+
+def edt(occupancy):
+    m = np.ascontiguousarray(occupancy, dtype=np.uint8)
+    edf = np.zeros((300, 300))
+    d2 = np.zeros((300, 300), dtype=np.uint32)
+    lib().cao_edt(_p(m), _p(edf), _p(d2))
+    return edf, d2
+
+
+def check_visibility(edf, a, b):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    return bool(lib().cao_ig_check_visibility(_p(edf), _p(a), _p(b)))
+
+
+def visible_cells(edf, pose, fov=FOV60, rng=5.0):
+    pose = np.ascontiguousarray(pose, dtype=np.float64)
+    mask = np.zeros(60, dtype=np.uint64)
+    lib().cao_ig_visible(_p(edf), _p(pose), fov, rng, _p(mask))
+    return mask
+
+
+def update_belief(belief, edf, poses, dets, ndet, fov=FOV60, rng=5.0):
+    poses = np.ascontiguousarray(poses, dtype=np.float64)
+    dets = np.ascontiguousarray(dets, dtype=np.float64)
+    ndet = np.ascontiguousarray(ndet, dtype=np.int32)
+    obs = np.zeros(60, dtype=np.uint64)
+    lib().cao_ig_update(_p(belief), _p(edf), poses.shape[0], _p(poses), _p(ndet), _p(dets), dets.shape[1], fov, rng,
+                        _p(obs))
+    return obs
+
+
+def mi_reward(belief, mask):
+    mask = np.ascontiguousarray(mask, dtype=np.uint64)
+    return lib().cao_ig_reward(_p(belief), _p(mask))
+
+
+def next_pose(edf, pose, action, xdt=5, dt=0.1, radius=0.5):
+    pose = np.ascontiguousarray(pose, dtype=np.float64)
+    action = np.ascontiguousarray(action, dtype=np.float64)
+    out = np.zeros(3)
+    ok = lib().cao_ig_next_pose(_p(edf), _p(pose), _p(action), xdt, dt, radius, _p(out))
+    return (out if ok else None)
+
+
+def rollout(belief, edf, pose0, observed0, exclude, n_steps, seed, q, sim, xdt=5, dt=0.1, radius=0.5, fov=FOV60,
+            rng=5.0):
+    pose0 = np.ascontiguousarray(pose0, dtype=np.float64)
+    observed0 = np.ascontiguousarray(observed0, dtype=np.uint64)
+    exclude = np.ascontiguousarray(exclude, dtype=np.uint64)
+    acts = np.zeros(n_steps, dtype=np.uint8)
+    pose = np.zeros(3)
+    r = lib().cao_ig_rollout(_p(belief), _p(edf), _p(pose0), _p(observed0), _p(exclude), n_steps, xdt, dt, radius,
+                             fov, rng, seed, q, sim, _p(acts), _p(pose))
+    return r, acts, pose

@@ -336,5 +336,108 @@ def main():
     save("obstacles_laserscan", cases)
 
 
+def ig_primitives():
+    """Golden vectors for the information-gain primitives: executed on the reference's
+    own Map / edfMap / targetMap / ig_mcts objects, parameters of experiments/src/dmcts.py:74-78."""
+    with rh.quiet():
+        from gym_collision_avoidance.envs.Map import Map
+        from gym_collision_avoidance.envs.information_models.edfMap import edfMap
+        from gym_collision_avoidance.envs.policies.ig_mcts import ig_mcts
+    rng = np.random.default_rng(4242)
+    worlds = {
+        "corridor": [(2, 2, 10, 10), (-10, 2, -2, 10), (2, -10, 10, -2), (-10, -10, -2, -2)],  # test_cases.py:3219-3222
+        "rects": [(-6.3, 1.2, -3.1, 4.4), (1.7, -8.2, 4.9, -5.5), (5.2, 3.3, 6.1, 9.7), (-1.4, -2.6, 0.8, -1.9)],
+    }
+    out = {}
+    for wname, obst in worlds.items():
+        with rh.quiet():
+            m = Map(30, 30, 0.1, [rect(*o) for o in obst])
+
+            class Ego(object):
+                radius = 0.5
+            pol = ig_mcts()
+            pol.set_param(ego_agent=Ego(), occ_map=m, map_size=(30, 30), detect_fov=60.0, map_res=0.1,
+                          detect_range=5.0, Ntree=5, Nsims=3, parallelize_sims=False, mcts_cp=1., mcts_horizon=4,
+                          parallelize_agents=False, dt=0.1, xdt=5, mcts_gamma=0.95, Ncycles=2)
+        tm, edf = pol.targetMap, pol.edfMap
+        out[wname + "__obstacles"] = np.asarray(obst, dtype=np.float64)
+        out[wname + "__edf"] = np.asarray(edf.map, dtype=np.float64)
+        # free-space poses (EDF > 0.3), plus the survey's known-answer poses
+        poses = [np.array([-5.0, 0.0, 0.0]), np.array([0.0, 0.0, 0.0]), np.array([-5.0, 0.0, 2.5])]
+        while len(poses) < 40:
+            p = np.append(rng.uniform(-13, 13, 2), rng.uniform(-np.pi, np.pi))
+            if edf.get_edf_value_from_pose(p) > 0.3:
+                poses.append(p)
+        poses = np.array(poses)
+        masks = np.zeros((len(poses), 60), dtype=np.uint64)
+        for q, p in enumerate(poses):
+            for (i, j) in tm.getVisibleCells(p):
+                masks[q, j] |= np.uint64(1) << np.uint64(i)
+        out[wname + "__vis_poses"] = poses
+        out[wname + "__vis_masks"] = masks
+        # checkVisibility on random point pairs
+        a = rng.uniform(-14, 14, (200, 2))
+        b = rng.uniform(-14, 14, (200, 2))
+        keep = np.array([edf.get_edf_value_from_pose(x) > 0.05 for x in a])
+        a, b = a[keep], b[keep]
+        out[wname + "__cv_a"], out[wname + "__cv_b"] = a, b
+        out[wname + "__cv_visible"] = np.array([bool(edf.checkVisibility(x, y)) for x, y in zip(a, b)])
+        # belief updates: 3 agents, 4 consecutive updates, detections near / far
+        bel, obsv, rew = [], [], []
+        upd_poses, upd_dets, upd_ndet = [], [], []
+        cur = poses[3:6].copy()
+        for step in range(4):
+            dets = []
+            for p in cur:
+                d = []
+                if rng.uniform() < 0.7:
+                    for _ in range(rng.integers(1, 3)):
+                        rr, aa = rng.uniform(0.5, 4.5), p[2] + rng.uniform(-0.5, 0.5)
+                        d.append(p[0:2] + rr * np.array([np.cos(aa), np.sin(aa)]))
+                dets.append(d)
+            cells = tm.update([p.copy() for p in cur], [list(d) for d in dets], frame='global')
+            mask = np.zeros(60, dtype=np.uint64)
+            for (i, j) in cells:
+                mask[j] |= np.uint64(1) << np.uint64(i)
+            bel.append(tm.map.copy())
+            obsv.append(mask)
+            rew.append(tm.get_reward_from_cells(cells))
+            dd = np.zeros((3, 2, 2))
+            nd = np.zeros(3, dtype=np.int32)
+            for k, d in enumerate(dets):
+                nd[k] = len(d)
+                for l, t in enumerate(d):
+                    dd[k, l] = t
+            upd_poses.append(cur.copy())
+            upd_dets.append(dd)
+            upd_ndet.append(nd)
+            cur = cur + np.array([0.3, 0.1, 0.15])
+        out[wname + "__upd_poses"], out[wname + "__upd_dets"] = np.array(upd_poses), np.array(upd_dets)
+        out[wname + "__upd_ndet"], out[wname + "__upd_belief"] = np.array(upd_ndet), np.array(bel)
+        out[wname + "__upd_observed"], out[wname + "__upd_reward"] = np.array(obsv), np.array(rew)
+        # MI of each visibility mask on the final belief
+        rws = []
+        for q in range(len(poses)):
+            cells = {(i, j) for j in range(60) for i in range(60) if (int(masks[q, j]) >> i) & 1}
+            rws.append(tm.get_reward_from_cells(cells))
+        out[wname + "__mi_reward"] = np.array(rws)
+        # get_next_pose for every primitive from every pose
+        acts = [np.array([v, w]) for v in (0.0, 2.0, 4.0) for w in (-0.5 * np.pi, 0, 0.5 * np.pi)]
+        nxt = np.full((len(poses), 9, 3), np.nan)
+        feas = np.zeros((len(poses), 9), dtype=bool)
+        for q, p in enumerate(poses):
+            for k, a_ in enumerate(acts):
+                r = pol.get_next_pose(p.copy(), a_)
+                if r is not None:
+                    nxt[q, k] = r
+                    feas[q, k] = True
+        out[wname + "__np_next"], out[wname + "__np_feasible"] = nxt, feas
+    path = os.path.join(HERE, "ig_primitives.npz")
+    np.savez_compressed(path, **out)
+    print("%-28s          %8.1f KB" % ("ig_primitives", os.path.getsize(path) / 1024))
+
+
 if __name__ == "__main__":
-    main()
+    if "--ig-only" not in sys.argv:
+        main()
+    ig_primitives()
