@@ -169,7 +169,8 @@ class BatchedCollisionAvoidanceEnv(object):
                 if not ptr:
                     continue
                 shape = shapes.get(name, (N, M))
-                st[name] = torch.as_tensor(_DevArray(ptr, shape, ts), device=self.device)
+                t = torch.as_tensor(_DevArray(ptr, shape, ts), device=self.device)
+                st[name] = t.view(torch.int32) if ts == "u4" else t  # uint32 has few torch kernels
             self._state = st
         return self._state
 

@@ -273,6 +273,17 @@ int cagym_get_state(void* env, cagym_state_ptrs* out) {
     return CAGYM_OK;
 }
 
+int cagym_ga3c_state(void* env, int max_observed, float* state, void* stream) {
+    Env* e = reinterpret_cast<Env*>(env);
+    if (!e) return fail(nullptr, CAGYM_E_INVALID, "null env");
+    if (!state || max_observed < 1 || max_observed > 10) return fail(e, CAGYM_E_INVALID, "bad arguments (max_observed in 1..10)");
+    size_t total = (size_t)e->cfg.n_worlds * e->cfg.max_agents;
+    hipLaunchKernelGGL(k_ga3c_state, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), e->D, max_observed, state);
+    HIPCHK(e, hipGetLastError());
+    return CAGYM_OK;
+}
+
 // ---- information-gain primitives -----------------------------------------------------------------
 static int ig_check(Env* e, const char* what) {
     if (!e) return fail(nullptr, CAGYM_E_INVALID, "null env");

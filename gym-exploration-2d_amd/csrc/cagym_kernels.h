@@ -490,3 +490,59 @@ __global__ void __launch_bounds__(256) k_rasterize(const double* obst, const int
         __syncthreads();
     }
 }
+
+// GA3CCADRLPolicy.agents_to_ga3c_cadrl_state (policies/GA3CCADRLPolicy.py:45-106): one lane per agent slot,
+// out[N,M,76] f32 = [id, n_others, dist_to_goal, heading_ego, pref_speed, radius, 10 x 7 other-agent features],
+// others ordered by (-round(d,2), p_orth), stable, last `max_observed` kept.  Zero rows for inactive slots.
+__global__ void __launch_bounds__(256) k_ga3c_state(CagymDev D, int max_observed, float* out) {
+    const size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= (size_t)D.N * D.M) return;
+    const int world = (int)(a / D.M), i = (int)(a - (size_t)world * D.M);
+    float* o = out + a * 76;
+    for (int q = 0; q < 76; q++) o[q] = 0.f;
+    const int n = D.n_agents[world];
+    if (i >= n) return;
+    const size_t base = (size_t)world * D.M;
+    const double px = D.px[a], py = D.py[a], ri = D.radius[a];
+    double gx = D.gx[a] - px, gy = D.gy[a] - py;
+    double dist = sqrt(gx * gx + gy * gy);
+    double prx = gx, pry = gy;
+    if (dist > 1e-8) { prx = gx / dist; pry = gy / dist; }
+    const double orx = -pry, ory = prx;
+    int cnt = n - 1;
+    const int drop = cnt > max_observed ? cnt - max_observed : 0;
+    int rows = 0;
+    for (int j = 0; j < n; j++) {
+        if (j == i) continue;
+        double dx = D.px[base + j] - px, dy = D.py[base + j] - py;
+        double rj = D.radius[base + j];
+        double ed = norm2(dx, dy) - ri - rj;
+        double k1 = -(rint(ed * 100.0) / 100.0), k2 = dot2(dx, dy, orx, ory);
+        int before = 0;  // others sorted strictly before j: smaller (k1, k2), ties by lower index (stable)
+        for (int l = 0; l < n; l++) {
+            if (l == i || l == j) continue;
+            double ex = D.px[base + l] - px, ey = D.py[base + l] - py;
+            double el = norm2(ex, ey) - ri - D.radius[base + l];
+            double l1 = -(rint(el * 100.0) / 100.0), l2 = dot2(ex, ey, orx, ory);
+            before += (l1 < k1) || (l1 == k1 && (l2 < k2 || (l2 == k2 && l < j)));
+        }
+        int row = before - drop;
+        if (row < 0) continue;
+        double vx = D.vx[base + j], vy = D.vy[base + j];
+        float* r = o + 6 + 7 * row;
+        r[0] = (float)dot2(dx, dy, prx, pry);
+        r[1] = (float)k2;
+        r[2] = (float)dot2(vx, vy, prx, pry);
+        r[3] = (float)dot2(vx, vy, orx, ory);
+        r[4] = (float)rj;
+        r[5] = (float)(ri + rj);
+        r[6] = (float)ed;
+        rows++;
+    }
+    o[0] = (float)i;
+    o[1] = (float)rows;
+    o[2] = (float)D.dist_goal[a];
+    o[3] = (float)D.heading_ego[a];
+    o[4] = (float)D.pref[a];
+    o[5] = (float)ri;
+}

@@ -1,0 +1,94 @@
+"""GA3C-CADRL policy on device: state-vector kernel (cagym_ga3c_state) + the network forward pass.
+
+Replaces policies/GA3CCADRLPolicy.py:34-43 and GA3C_CADRL/network.py:65-98 (TensorFlow 1.15 session.run per
+agent) by one batched forward over every GA3C agent of every world.  The GEMMs are plain library GEMMs
+(torch -> hipBLASLt/rocBLAS, fp32 like the reference's TF graph); weights come from the converted checkpoint
+(tools/convert_ga3c_checkpoint.py -> weights/ga3c_cadrl_*.npz).  TF1 LSTMCell conventions: gate order
+(i, j, f, o), forget_bias 1.0, input concat[x, h], state frozen beyond sequence_length.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import scenarios as sc
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+# network.py:125-148
+AVG = np.hstack([[0.0], [0.0, 0.0, 1.0, 0.5], np.tile([0.0, 0.0, 0.0, 0.0, 0.5, 0.0, 1.0], 10)]).astype(np.float32)
+STD = np.hstack([[1.0], [5.0, 3.14, 1.0, 1.0], np.tile([5.0, 5.0, 1.0, 1.0, 1.0, 5.0, 1.0], 10)]).astype(np.float32)
+
+
+def action_table():
+    """network.Actions (network.py:8-17): 11 rows (speed factor, delta heading)."""
+    rows = [(1.0, -np.pi / 6 + k * (np.pi / 12)) for k in range(5)]
+    rows += [(0.5, -np.pi / 6 + k * (np.pi / 6)) for k in range(3)]
+    rows += [(0.0, -np.pi / 6 + k * (np.pi / 6)) for k in range(3)]
+    return np.array(rows, dtype=np.float64)
+
+
+class GA3CCADRLPolicy(object):
+    def __init__(self, benv, checkpoint="iros18", max_observed=None):
+        self.b = benv
+        self.L = benv.L
+        self.L.cagym_ga3c_state.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        path = checkpoint if os.path.exists(checkpoint) else os.path.join(HERE, "weights", "ga3c_cadrl_%s.npz" % checkpoint)
+        W = np.load(path)
+        dev = benv.device
+        self.W = {k: torch.from_numpy(np.ascontiguousarray(W[k])).to(dev) for k in W.files}
+        self.avg = torch.from_numpy(AVG).to(dev)
+        self.std = torch.from_numpy(STD).to(dev)
+        self.table = torch.from_numpy(action_table()).to(dev)
+        self.max_observed = int(max_observed if max_observed is not None else min(benv.M - 1, 10))
+        self.state = torch.zeros((benv.N, benv.M, 76), dtype=torch.float32, device=dev)
+        self._is_ga3c = None
+
+    def states(self):
+        with torch.cuda.device(self.b.device):
+            rc = self.L.cagym_ga3c_state(self.b.h, self.max_observed, self.state.data_ptr(), self.b._stream())
+        _lib.check(self.L, self.b.h, rc, "cagym_ga3c_state")
+        return self.state
+
+    def forward(self, x75):
+        """softmax_p [B, 11] for NN inputs x75 [B, 75] (= state[..., 1:])."""
+        W = self.W
+        x = x75.float()
+        xn = (x - self.avg) / self.std
+        B = x.shape[0]
+        n = x[:, 0].to(torch.int32)
+        h = torch.zeros((B, 64), dtype=torch.float32, device=x.device)
+        c = torch.zeros_like(h)
+        seq = xn[:, 5:].reshape(B, 10, 7)
+        for t in range(10):
+            z = torch.cat([seq[:, t], h], dim=1) @ W["lstm_kernel"] + W["lstm_bias"]
+            i, j, f, o = z.split(64, dim=1)
+            c2 = torch.sigmoid(f + 1.0) * c + torch.sigmoid(i) * torch.tanh(j)
+            h2 = torch.sigmoid(o) * torch.tanh(c2)
+            live = (t < n).unsqueeze(1)
+            c = torch.where(live, c2, c)
+            h = torch.where(live, h2, h)
+        y = torch.relu(torch.cat([xn[:, 1:5], h], dim=1) @ W["l1_kernel"] + W["l1_bias"])
+        y = torch.relu(y @ W["l2_kernel"] + W["l2_bias"])
+        y = torch.relu(y @ W["fc1_kernel"] + W["fc1_bias"])
+        p = torch.softmax(y @ W["logits_kernel"] + W["logits_bias"], dim=1)
+        return (p + 1e-4) / (1.0 + 1e-4 * 11)
+
+    def act(self, ext_actions=None):
+        """Fill ext_actions [N,M,2] f32 with (pref_speed * a0, a1) for every agent whose policy id is
+        POLICY_GA3C (GA3CCADRLPolicy.find_next_action, :34-43); other rows are left untouched."""
+        b = self.b
+        if ext_actions is None:
+            ext_actions = torch.zeros((b.N, b.M, 2), dtype=torch.float32, device=b.device)
+        st = self.states()
+        status = b.state()["status"]
+        is_ga3c = ((status >> 8) & 15) == sc.POLICY_GA3C
+        idx = is_ga3c.reshape(-1).nonzero(as_tuple=True)[0]
+        if idx.numel():
+            s = st.reshape(-1, 76)[idx]
+            p = self.forward(s[:, 1:])
+            a = self.table[p.argmax(dim=1)]
+            act = torch.stack([s[:, 4].double() * a[:, 0], a[:, 1]], dim=1).float()
+            ext_actions.reshape(-1, 2)[idx] = act
+        return ext_actions

@@ -140,6 +140,13 @@ int cagym_get_state(void* env, cagym_state_ptrs* out);
 /* LaserScanSensor.sense (sensors/LaserScanSensor.py:27-58) on the current state -> laserscan [N,M,16]. */
 int cagym_laserscan(void* env, float* laserscan, void* stream);
 
+/* GA3CCADRLPolicy.agents_to_ga3c_cadrl_state (policies/GA3CCADRLPolicy.py:45-106) for every active agent:
+ * state DEVICE [N,M,76] f32 = [id, n_others, dist_to_goal, heading_ego, pref_speed, radius, 10 x (p_prll,
+ * p_orth, v_prll, v_orth, r_other, r_host+r_other, edge distance)], others sorted by (-round(d,2), p_orth),
+ * the closest `max_observed` (Config.MAX_NUM_OTHER_AGENTS_OBSERVED, <= 10) kept, farthest first.  The network
+ * itself (LSTM-64 + 3 x FC-256, network.py:65-98) is evaluated by the host policy on state[:, :, 1:]. */
+int cagym_ga3c_state(void* env, int max_observed, float* state, void* stream);
+
 /* ---- information-gain planner primitives (cfg 5).  All pointers DEVICE.  A visibility set is a
  * [60] u64 mask: bit i of word j <=> belief cell (i, j) (x index i, y index j; 0.5 m cells over 30x30 m). ---- */
 

@@ -700,3 +700,61 @@ void cao_step(cao_env* e, const double* ext_actions) {
         done_world(e, w);
     }
 }
+
+/* GA3CCADRLPolicy.agents_to_ga3c_cadrl_state (policies/GA3CCADRLPolicy.py:45-106), RNN architecture:
+ * out[N,M,76] = [id, n_others, dist_to_goal, heading_ego, pref_speed, radius, 10 x (p_prll, p_orth, v_prll,
+ * v_orth, r_other, r_host + r_other, edge distance)]; others sorted by (-round(d, 2), p_orth) (stable), the
+ * last max_observed kept (farthest first, closest last).  round() is NumPy's: rint(x * 100) / 100. */
+void cao_ga3c_states(cao_env* e, int max_observed, double* out) {
+    int M = e->M;
+    memset(out, 0, (size_t)e->N * M * 76 * sizeof(double));
+    for (int w = 0; w < e->N; w++) {
+        int n = e->nagents[w];
+        size_t base = (size_t)w * M;
+        for (int i = 0; i < n; i++) {
+            size_t a = base + i;
+            double* o = out + a * 76;
+            const double* P = e->f[CAO_F_POS];
+            const double* prll = e->f[CAO_F_REF_PRLL] + 2 * a;
+            const double* orth = e->ref_orth + 2 * a;
+            int idx[64], cnt = 0;
+            double k1[64], k2[64];
+            for (int j = 0; j < n; j++) {
+                if (j == i) continue;
+                double dx = P[2 * (base + j)] - P[2 * a], dy = P[2 * (base + j) + 1] - P[2 * a + 1];
+                double d2 = norm2(dx, dy) - e->radius[a] - e->radius[base + j];
+                idx[cnt] = j;
+                k1[cnt] = -(rint(d2 * 100.0) / 100.0);
+                k2[cnt] = dot2(dx, dy, orth[0], orth[1]);
+                cnt++;
+            }
+            for (int p = 1; p < cnt; p++) { /* stable insertion sort by (k1, k2) */
+                int ji = idx[p]; double a1 = k1[p], a2 = k2[p]; int q = p - 1;
+                while (q >= 0 && (k1[q] > a1 || (k1[q] == a1 && k2[q] > a2))) {
+                    idx[q + 1] = idx[q]; k1[q + 1] = k1[q]; k2[q + 1] = k2[q]; q--;
+                }
+                idx[q + 1] = ji; k1[q + 1] = a1; k2[q + 1] = a2;
+            }
+            int start = cnt > max_observed ? cnt - max_observed : 0, row = 0;
+            o[0] = (double)i;
+            o[2] = e->f[CAO_F_DIST_TO_GOAL][a];
+            o[3] = e->f[CAO_F_HEADING_EGO][a];
+            o[4] = e->pref_speed[a];
+            o[5] = e->radius[a];
+            for (int p = start; p < cnt; p++, row++) {
+                size_t b = base + idx[p];
+                double dx = P[2 * b] - P[2 * a], dy = P[2 * b + 1] - P[2 * a + 1];
+                const double* v = e->f[CAO_F_VEL] + 2 * b;
+                double* r = o + 6 + 7 * row;
+                r[0] = dot2(dx, dy, prll[0], prll[1]);
+                r[1] = dot2(dx, dy, orth[0], orth[1]);
+                r[2] = dot2(v[0], v[1], prll[0], prll[1]);
+                r[3] = dot2(v[0], v[1], orth[0], orth[1]);
+                r[4] = e->radius[b];
+                r[5] = e->radius[a] + e->radius[b];
+                r[6] = norm2(dx, dy) - e->radius[a] - e->radius[b];
+            }
+            o[1] = (double)row;
+        }
+    }
+}

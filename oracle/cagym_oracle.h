@@ -77,6 +77,9 @@ void cao_orca_action(int M, int ego, const double* pos, const double* vel, const
                      const double* pref_speed, const double* radius, double heading, double collab,
                      double dt, double* action_out);
 
+/* GA3C-CADRL state vectors out[N,M,76] (policies/GA3CCADRLPolicy.py:45-106) */
+void cao_ga3c_states(cao_env* e, int max_observed, double* out);
+
 /* ---- information-gain primitives (cagym_oracle_ig.c); one world at a time ---- */
 /* edfMap.update (information_models/edfMap.py:11-12): edf[300*300] f64 and/or d2[300*300] u32 */
 void cao_edt(const uint8_t* map300, double* edf, uint32_t* d2);

@@ -1,0 +1,48 @@
+"""fp64 numpy restatement of the GA3C-CADRL forward pass (TEST INFRASTRUCTURE ONLY).
+
+policies/GA3C_CADRL/network.py:65-98 (NetworkVP_rnn), :8-17 (Actions), :125-148 (normalisation) of the
+reference; TensorFlow 1.15 is absent, so network outputs are "parity unpinned": the only pin is the known
+answer recorded in SURVEY.md 8(c) (reproduced in tests/test_ga3c.py) plus behaviour (agents reach goals).
+TF1 LSTMCell conventions: gates (i, j, f, o), forget_bias 1.0, input = concat[x, h].
+"""
+import numpy as np
+
+AVG = np.hstack([[0.0], [0.0, 0.0, 1.0, 0.5], np.tile([0.0, 0.0, 0.0, 0.0, 0.5, 0.0, 1.0], 10)])
+STD = np.hstack([[1.0], [5.0, 3.14, 1.0, 1.0], np.tile([5.0, 5.0, 1.0, 1.0, 1.0, 5.0, 1.0], 10)])
+
+
+def action_table():
+    a = np.mgrid[1.0:1.1:0.5, -np.pi / 6:np.pi / 6 + 0.01:np.pi / 12].reshape(2, -1).T
+    a = np.vstack([a, np.mgrid[0.5:0.6:0.5, -np.pi / 6:np.pi / 6 + 0.01:np.pi / 6].reshape(2, -1).T])
+    return np.vstack([a, np.mgrid[0.0:0.1:0.5, -np.pi / 6:np.pi / 6 + 0.01:np.pi / 6].reshape(2, -1).T])
+
+
+def _sig(x):
+    return 1.0 / (1.0 + np.exp(-x))
+
+
+def forward(W, x75):
+    """x75: [B, 75] = state[1:].  Returns softmax_p [B, 11] in fp64."""
+    x = np.asarray(x75, dtype=np.float64)
+    xn = (x - AVG) / STD
+    B = x.shape[0]
+    n = x[:, 0].astype(np.int64)
+    h = np.zeros((B, 64))
+    c = np.zeros((B, 64))
+    seq = xn[:, 5:].reshape(B, 10, 7)
+    K, b = W["lstm_kernel"].astype(np.float64), W["lstm_bias"].astype(np.float64)
+    for t in range(10):
+        z = np.concatenate([seq[:, t], h], axis=1) @ K + b
+        i, j, f, o = np.split(z, 4, axis=1)
+        c2 = _sig(f + 1.0) * c + _sig(i) * np.tanh(j)
+        h2 = _sig(o) * np.tanh(c2)
+        live = (t < n)[:, None]
+        c = np.where(live, c2, c)
+        h = np.where(live, h2, h)
+    y = np.maximum(0, np.concatenate([xn[:, 1:5], h], axis=1) @ W["l1_kernel"].astype(np.float64) + W["l1_bias"])
+    y = np.maximum(0, y @ W["l2_kernel"].astype(np.float64) + W["l2_bias"])
+    y = np.maximum(0, y @ W["fc1_kernel"].astype(np.float64) + W["fc1_bias"])
+    lg = y @ W["logits_kernel"].astype(np.float64) + W["logits_bias"]
+    p = np.exp(lg - lg.max(axis=1, keepdims=True))
+    p /= p.sum(axis=1, keepdims=True)
+    return (p + 1e-4) / (1.0 + 1e-4 * 11)

@@ -55,6 +55,7 @@ def lib():
             getattr(L, n).argtypes = [C.c_void_p, C.c_int]
         L.cao_rasterize.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.cao_orca_action.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_double] * 3 + [C.c_void_p]
+        L.cao_ga3c_states.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.cao_edt.argtypes = [C.c_void_p] * 3
         L.cao_ig_check_visibility.argtypes = [C.c_void_p] * 3
         L.cao_ig_visible.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p]
@@ -136,6 +137,11 @@ class OracleEnv(object):
 
     def i(self, name):
         return np.ctypeslib.as_array(self.L.cao_i32(self.h, I[name]), shape=(self.N, self.M))
+
+    def ga3c_states(self, max_observed=None):
+        out = np.zeros((self.N, self.M, 76))
+        self.L.cao_ga3c_states(self.h, self.K if max_observed is None else int(max_observed), _p(out))
+        return out
 
 
 def rasterize(obstacles):

@@ -437,7 +437,52 @@ def ig_primitives():
     print("%-28s          %8.1f KB" % ("ig_primitives", os.path.getsize(path) / 1024))
 
 
+def ga3c_states():
+    """State vectors from the reference's own agents_to_ga3c_cadrl_state (policies/GA3CCADRLPolicy.py:45-106),
+    called unbound on live Agent objects (TensorFlow is absent, only this numpy half can be executed)."""
+    with rh.quiet():
+        from gym_collision_avoidance.envs.policies.GA3CCADRLPolicy import GA3CCADRLPolicy
+    U, NC = scen.DYN_UNICYCLE, scen.POLICY_NONCOOP
+    out = {}
+
+    class Dummy(object):
+        pass
+    for name, M, seed, steps in (("m4", 4, 11, 25), ("m10", 10, 12, 40), ("m7", 7, 13, 30)):
+        w = scen.random_world(np.random.default_rng(seed), M)
+        set_max_agents(10)
+        Config.EVALUATE_MODE = True
+        with rh.quiet():
+            agents = [Agent(w[i, 0], w[i, 1], w[i, 2], w[i, 3], w[i, 5], w[i, 4],
+                            np.float64(np.arctan2(w[i, 3] - w[i, 1], w[i, 2] - w[i, 0])), POLICIES[NC], DYNAMICS[U],
+                            [OtherAgentsStatesSensor], i) for i in range(M)]
+            for a in agents:
+                a.policy.targetMap = None
+            env = OracleEnv()
+            env.set_agents(agents)
+            env.reset()
+        states = []
+        for t in range(steps + 1):
+            if t:
+                with rh.quiet():
+                    env.step({})
+            st = np.zeros((M, 76))
+            for i in range(M):
+                st[i] = GA3CCADRLPolicy.agents_to_ga3c_cadrl_state(Dummy(), env.agents[i],
+                                                                   env.agents[:i] + env.agents[i + 1:])
+            states.append(st)
+        out[name + "__agents6"] = w
+        out[name + "__states"] = np.array(states)
+    path = os.path.join(HERE, "ga3c_states.npz")
+    np.savez_compressed(path, **out)
+    print("%-28s          %8.1f KB" % ("ga3c_states", os.path.getsize(path) / 1024))
+
+
 if __name__ == "__main__":
+    if "--ga3c-only" in sys.argv:
+        ga3c_states()
+        sys.exit(0)
     if "--ig-only" not in sys.argv:
         main()
     ig_primitives()
+    if "--ig-only" not in sys.argv:
+        ga3c_states()
