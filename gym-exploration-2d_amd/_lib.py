@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "libcagym_hip.so")
+LIB_PATH = os.environ.get("CAGYM_LIB") or os.path.join(HERE, "csrc", "libcagym_hip.so")  # CAGYM_LIB: diagnostic builds
 
 EGO_WIDTH = 12
 FLAG_AT_GOAL, FLAG_IN_COLLISION, FLAG_RAN_OUT_OF_TIME, FLAG_DONE = 1, 2, 4, 8

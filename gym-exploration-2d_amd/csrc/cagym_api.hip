@@ -9,6 +9,7 @@
 
 #include "../../include/cagym.h"
 #include "cagym_kernels.h"
+#include "cagym_kernels2.h"
 #include "cagym_ig.h"
 
 namespace {
@@ -26,6 +27,8 @@ struct Env {
     IgDev G{};
     uint32_t* ig_any = nullptr;
     bool ig_ready = false;
+    int any_rvo = 1;
+    int generation = 2;  // CAGYM_KERNEL=v1 selects the one-lane-per-agent kernels (A/B only)
 };
 
 int fail(Env* e, int code, const std::string& msg) {
@@ -136,6 +139,21 @@ int cagym_create(const cagym_config* cfg, void** env_out) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_reset), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    {
+        const char* g = getenv("CAGYM_KERNEL");
+        if (g && (!strcmp(g, "v1") || !strcmp(g, "1"))) e->generation = 1;
+        int lds2 = (int)cagym_lds2_bytes((int)M);
+        if (lds2 > 160 * 1024) e->generation = 1;
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<256>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<512>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<512>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<256, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<512, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<512, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<256, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<512, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<512, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+    }
     (void)hipGetLastError();
     *env_out = e;
     return CAGYM_OK;
@@ -164,6 +182,9 @@ int cagym_set_scenarios(void* env, const double* agents6, const double* heading0
         if (policy_id[k] < 0 || policy_id[k] > CAGYM_POL_IGMCTS) return fail(e, CAGYM_E_INVALID, "policy id out of range");
         if (dynamics_id[k] < 0 || dynamics_id[k] > CAGYM_DYN_FIRSTORDER) return fail(e, CAGYM_E_INVALID, "dynamics id out of range");
     }
+    e->any_rvo = 0;
+    for (size_t k = 0; k < SM; k++)
+        if (policy_id[k] == CAGYM_POL_RVO) e->any_rvo = 1;
     std::vector<int32_t> na(S), no(S, 0);
     for (size_t s = 0; s < S; s++) {
         na[s] = n_agents ? n_agents[s] : (int32_t)M;
@@ -223,6 +244,13 @@ int cagym_step(void* env, const float* ext_actions, const cagym_outputs* out, vo
     if (!e->scenarios_set) return fail(e, CAGYM_E_STATE, "cagym_step before cagym_set_scenarios");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     CagymOut o = to_out(out);
+    const int M = e->cfg.max_agents;
+    if (e->generation == 2) {
+        const size_t lds2 = cagym_lds2_bytes(M);
+        if (M <= 12) hipLaunchKernelGGL((k_step2<256>), dim3(n_waves(e)), dim3(256), lds2, st, e->D, ext_actions, o, e->any_rvo);
+        else if (M <= 16) hipLaunchKernelGGL((k_step2<512>), dim3(n_waves(e)), dim3(512), lds2, st, e->D, ext_actions, o, e->any_rvo);
+        else hipLaunchKernelGGL((k_step2<512>), dim3(n_waves(e)), dim3(512), lds2, st, e->D, ext_actions, o, e->any_rvo);
+    } else
     hipLaunchKernelGGL(k_step, dim3(n_waves(e)), dim3(64), cagym_lds_bytes(e->cfg.max_agents), st, e->D, ext_actions, o);
     HIPCHK(e, hipGetLastError());
     if (e->cfg.laserscan && o.laserscan) return cagym_laserscan(env, o.laserscan, stream);
@@ -239,7 +267,19 @@ int cagym_rollout(void* env, int n_steps, int auto_reset, const cagym_outputs* o
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     CagymOut o = to_out(out);
     size_t lds = cagym_lds_bytes(e->cfg.max_agents);
-    if (auto_reset)
+    const int M = e->cfg.max_agents;
+    if (e->generation == 2) {
+        const size_t lds2 = cagym_lds2_bytes(M);
+        const dim3 g(n_waves(e));
+#define ROLL2(NT)                                                                                                  \
+    do {                                                                                                           \
+        if (auto_reset) hipLaunchKernelGGL((k_rollout2<NT, true>), g, dim3(NT), lds2, st, e->D, n_steps, o, e->any_rvo); \
+        else hipLaunchKernelGGL((k_rollout2<NT, false>), g, dim3(NT), lds2, st, e->D, n_steps, o, e->any_rvo);         \
+    } while (0)
+        if (M <= 12) ROLL2(256);
+        else ROLL2(512);
+#undef ROLL2
+    } else if (auto_reset)
         hipLaunchKernelGGL(k_rollout<true>, dim3(n_waves(e)), dim3(64), lds, st, e->D, n_steps, o);
     else
         hipLaunchKernelGGL(k_rollout<false>, dim3(n_waves(e)), dim3(64), lds, st, e->D, n_steps, o);
@@ -283,6 +323,17 @@ int cagym_ga3c_state(void* env, int max_observed, float* state, void* stream) {
     HIPCHK(e, hipGetLastError());
     return CAGYM_OK;
 }
+
+#ifdef CAGYM_STAMPS
+int cagym_debug_stamps(unsigned long long* out16, int reset) {
+    if (out16) hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 16);
+    if (reset) {
+        unsigned long long z[16] = {0};
+        hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z));
+    }
+    return 0;
+}
+#endif
 
 // ---- information-gain primitives -----------------------------------------------------------------
 static int ig_check(Env* e, const char* what) {

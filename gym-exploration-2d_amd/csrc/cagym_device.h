@@ -59,6 +59,7 @@ struct CagymOut {
 // Per-lane agent record held in registers across a step (and across steps in the rollout).
 struct Agent {
     double px, py, vx, vy, h, he, dg, trem, t, gx, gy, r, pref, speed, dh, aux0, aux1, coop;
+    double prx, pry;  // ref_prll (agent.py:250-269) of the last update_ego_frame; derived, never stored
     float a0, a1;
     uint32_t st;  // CAGYM_FLAG_* | policy << 8 | dyn << 12
     int step;
@@ -95,6 +96,8 @@ __device__ __forceinline__ void update_ego_frame(Agent& A, double& prx, double& 
         prx = gx / dist;
         pry = gy / dist;
     }
+    A.prx = prx;
+    A.pry = pry;
     double ang = atan2(pry, prx);
     A.he = wrap_angle(A.h - ang);
 }
@@ -143,6 +146,7 @@ __device__ __forceinline__ void load_agent(const CagymDev& D, Agent& A, size_t a
     A.aux0 = D.aux0[a]; A.aux1 = D.aux1[a]; A.coop = D.coop[a];
     A.a0 = D.action[2 * a]; A.a1 = D.action[2 * a + 1];
     A.st = D.status[a]; A.step = D.step_num[a];
+    ref_axes(A, A.prx, A.pry);  // same expression as update_ego_frame at the agent's last move (pos/goal unchanged)
 }
 
 __device__ __forceinline__ void store_agent(const CagymDev& D, const Agent& A, size_t a, bool constants) {

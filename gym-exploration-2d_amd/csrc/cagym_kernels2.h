@@ -1,0 +1,500 @@
+// cagym_kernels2.h -- phase-split env.step() kernels (generation 2).
+//
+// Why: with one lane per agent a 4096 x 10 batch is 683 lone waves on 1024 SIMDs; SQ counters showed
+// ~11.5 k instructions per wave-step, ~85 % of them the O(M^2) neighbour loops, 47 % of cycles in waits
+// (profiles/r1/*pmc_sq.txt).  Here a workgroup of NT threads owns the same wpw = 64/M worlds, and a step
+// alternates between
+//   S phases: lane-dense PER-AGENT work on wave 0 (policy/LP solve, dynamics, reward, done, reset), and
+//   P phases: lane-dense PER-PAIR work on all NT lanes (ORCA half-planes + neighbour ranks, pair
+//             distances / collision tests, OAS sort ranks and rows),
+// separated by workgroup barriers, so the serial chain per step is ~10x shorter and several waves per
+// SIMD overlap each other's latency.  Arithmetic is shared with generation 1 (cagym_device.h,
+// cagym_orca.h): both generations produce bit-identical results (tests/test_hip_parity.py).
+#pragma once
+#include "cagym_kernels.h"
+
+// Diagnostic build only (-DCAGYM_STAMPS, never the shipped library): thread 0 of workgroup 0 accumulates
+// s_memtime deltas per phase into g_stamps; read back with cagym_debug_stamps().  The stamp values leave
+// the kernel only through this buffer and feed no output.
+#ifdef CAGYM_STAMPS
+__device__ unsigned long long g_stamps[16];
+#define STAMP(i)                                                                  \
+    do {                                                                          \
+        if (threadIdx.x == 0 && blockIdx.x == 0) {                                \
+            unsigned long long _t = __builtin_amdgcn_s_memtime();                 \
+            g_stamps[i] += _t - stamp_prev;                                       \
+            stamp_prev = _t;                                                      \
+        }                                                                         \
+    } while (0)
+#define STAMP_BEGIN() unsigned long long stamp_prev = __builtin_amdgcn_s_memtime()
+#else
+#define STAMP(i) do { } while (0)
+#define STAMP_BEGIN() do { } while (0)
+#endif
+
+struct Lds2 {
+    double *tpx, *tpy, *tvx, *tvy, *tr, *tprx, *tpry;  // [64] agent tile
+    float* tcoop;                                        // [64]
+    uint32_t* tst;                                       // [64]
+    int* wn;                                             // [32] agents per world of this workgroup
+    int* flag;                                           // [4]  0: any world reset this step
+    float2* lpv;                                         // [64] LP velocity of each agent (in/out of LP3)
+    int* lpk;                                            // [64] line where linearProgram2 failed (or nn)
+    float* lpr;                                          // [64] maxSpeed of the ego (LP radius)
+    unsigned long long* lpmask;                          // [1]  agents that need linearProgram3
+    // union, pre-move view.  Rows are padded to MP = roundup(M, 4) entries and unused entries hold
+    // sentinels, so the rank loops are branch-free 16-byte LDS reads.
+    float* dsq;      // [64*MP]   squared centre distance ego->neighbour (+inf = not a neighbour)
+    float4* lines;   // [64*MP]   half-plane of (ego, neighbour), unsorted
+    float4* sorted;  // [10][64]  half-planes nearest-first
+    float4* proj;    // [10][64]  linearProgram3 scratch
+    // union, post-move view
+    double* keys;  // [64*MP]   OAS sort key (-inf = not observed)
+    double* gap;   // [64*MP]   d - (r_i + r_j) for the lower index of a pair, else +inf
+    uint8_t* hit;  // [64*MP]   pair collides
+    float* oas;    // [64*(M-1)*10]
+};
+
+__host__ __device__ inline size_t a16(size_t x) { return (x + 15) & ~(size_t)15; }
+__host__ __device__ inline int cagym_mp(int M) { return (M + 3) & ~3; }
+
+__host__ __device__ inline size_t cagym_lds2_bytes(int M) {
+    const size_t MP = cagym_mp(M);
+    size_t head = 7 * 64 * 8 + 64 * 4 + 64 * 4 + 32 * 4 + 16 + 64 * 8 + 64 * 4 + 64 * 4 + 16;
+    size_t pre = 64 * MP * 4 + 64 * MP * 16 + 2 * (size_t)CAGYM_MAXNB * 64 * 16;
+    size_t post = 2 * 64 * MP * 8 + 64 * MP + (size_t)64 * (M - 1) * 40;
+    return a16(head) + (pre > post ? pre : post);
+}
+
+__device__ __forceinline__ Lds2 carve_lds2(unsigned char* smem, int M) {
+    Lds2 W;
+    const size_t MP = cagym_mp(M);
+    W.tpx = reinterpret_cast<double*>(smem);
+    W.tpy = W.tpx + 64; W.tvx = W.tpy + 64; W.tvy = W.tvx + 64; W.tr = W.tvy + 64; W.tprx = W.tr + 64; W.tpry = W.tprx + 64;
+    W.tcoop = reinterpret_cast<float*>(W.tpry + 64);
+    W.tst = reinterpret_cast<uint32_t*>(W.tcoop + 64);
+    W.wn = reinterpret_cast<int*>(W.tst + 64);
+    W.flag = W.wn + 32;
+    W.lpv = reinterpret_cast<float2*>(W.flag + 4);
+    W.lpk = reinterpret_cast<int*>(W.lpv + 64);
+    W.lpr = reinterpret_cast<float*>(W.lpk + 64);
+    W.lpmask = reinterpret_cast<unsigned long long*>(W.lpr + 64);
+    size_t head = 7 * 64 * 8 + 64 * 4 + 64 * 4 + 32 * 4 + 16 + 64 * 8 + 64 * 4 + 64 * 4 + 16;
+    unsigned char* u = smem + a16(head);
+    W.dsq = reinterpret_cast<float*>(u);
+    W.lines = reinterpret_cast<float4*>(u + 64 * MP * 4);
+    W.sorted = W.lines + 64 * MP;
+    W.proj = W.sorted + CAGYM_MAXNB * 64;
+    W.keys = reinterpret_cast<double*>(u);
+    W.gap = W.keys + 64 * MP;
+    W.hit = reinterpret_cast<uint8_t*>(W.gap + 64 * MP);
+    W.oas = reinterpret_cast<float*>(W.hit + 64 * MP);
+    return W;
+}
+
+__device__ __forceinline__ void publish_tile2(const Lds2& W, const Agent& A, int lane) {
+    W.tpx[lane] = A.px; W.tpy[lane] = A.py; W.tvx[lane] = A.vx; W.tvy[lane] = A.vy; W.tr[lane] = A.r;
+    W.tcoop[lane] = (float)A.coop;
+    W.tst[lane] = A.st;
+}
+
+// pair slot p = agent * M + j  ->  (agent lane a, neighbour slot j, world_local wl, agent slot sl)
+struct PairIdx {
+    int a, j, wl, sl;
+};
+__device__ __forceinline__ PairIdx pair_of(int p, int M, uint32_t inv_m) {
+    PairIdx q;
+    q.a = (int)__umulhi((uint32_t)p, inv_m);  // p / M for p < 2^16 (inv_m = 2^32 / M + 1)
+    q.j = p - q.a * M;
+    q.wl = (int)__umulhi((uint32_t)q.a, inv_m);
+    q.sl = q.a - q.wl * M;
+    return q;
+}
+
+// One env.step() of the workgroup's worlds.  Agent registers A live on wave 0 (tid < 64) only; the pair
+// phases keep nothing in registers across barriers (everything is re-read from LDS).
+template <int NT, bool AUTO_RESET>
+__device__ inline void step_core2(const CagymDev& D, const Lds2& W, LaneCtx& C, Agent& A, const float* ext,
+                                  const CagymOut& out, float& ep_ret, int& ep_len, bool any_rvo) {
+    const int tid = threadIdx.x, M = D.M, K = M - 1, MP = cagym_mp(M);
+    const uint32_t inv_m = (uint32_t)(0x100000000ull / (uint32_t)M) + 1u;
+    const bool agent_lane = tid < CAGYM_WAVE;
+    const size_t aidx = (size_t)C.world * M + C.slot;
+    const int npairs = C.wpw * M * M;
+    STAMP_BEGIN();
+    // ---- S0: publish the pre-move tile ---------------------------------------------------------------
+    if (agent_lane) {
+        publish_tile2(W, A, tid);
+        if (C.wl < C.wpw && C.slot == 0) W.wn[C.wl] = C.valid ? C.n : 0;
+    }
+    __syncthreads();
+    STAMP(0);
+    // ---- P1: ORCA half-planes, one lane per (ego, neighbour) -------------------------------------------
+    if (any_rvo) {
+        for (int p = tid; p < npairs; p += NT) {
+            const PairIdx q = pair_of(p, M, inv_m);
+            const int n = W.wn[q.wl];
+            const uint32_t st = W.tst[q.a];
+            const bool on = q.sl < n && q.j < n && q.j != q.sl && ST_POLICY(st) == CAGYM_POL_RVO && !(st & CAGYM_FLAG_DONE);
+            float dq = INFINITY;
+            if (on) {
+                const int b = q.a - q.sl + q.j;
+                const float pex = (float)W.tpx[q.a], pey = (float)W.tpy[q.a];
+                const float dx = pex - (float)W.tpx[b], dy = pey - (float)W.tpy[b];
+                dq = dx * dx + dy * dy;
+                W.lines[q.a * MP + q.j] = orca_line(pex, pey, (float)W.tvx[q.a], (float)W.tvy[q.a],
+                                                    (float)((1 + 15e-2) * W.tr[q.a]), W.tcoop[q.a], (float)D.dt,
+                                                    W.tpx[b], W.tpy[b], W.tvx[b], W.tvy[b], W.tr[b]);
+            }
+            W.dsq[q.a * MP + q.j] = dq;
+            if (q.j == M - 1)
+                for (int l = M; l < MP; l++) W.dsq[q.a * MP + l] = INFINITY;
+        }
+        __syncthreads();
+        STAMP(1);
+        for (int p = tid; p < npairs; p += NT) {
+            const PairIdx q = pair_of(p, M, inv_m);
+            const float dq = W.dsq[q.a * MP + q.j];
+            if (!(dq < INFINITY)) continue;
+            // rank among the ego's neighbours: nearest first, ties by lower index (Agent::insertAgentNeighbor)
+            int rank = 0;
+            const float4* row = reinterpret_cast<const float4*>(W.dsq + q.a * MP);
+            for (int l4 = 0; l4 < MP; l4 += 4) {
+                const float4 v = row[l4 >> 2];
+                rank += (v.x < dq) || (v.x == dq && l4 + 0 < q.j);
+                rank += (v.y < dq) || (v.y == dq && l4 + 1 < q.j);
+                rank += (v.z < dq) || (v.z == dq && l4 + 2 < q.j);
+                rank += (v.w < dq) || (v.w == dq && l4 + 3 < q.j);
+            }
+            if (rank < CAGYM_MAXNB) W.sorted[rank * CAGYM_WAVE + q.a] = W.lines[q.a * MP + q.j];
+        }
+        __syncthreads();
+        STAMP(2);
+    }
+    // ---- S1: _take_action (env.py:287-340).  RVO: linearProgram2 per agent lane, then the (rare, long)
+    //      linearProgram3 of the infeasible agents cooperatively on 16-lane groups of every wave ------------
+    if (any_rvo) {
+        if (agent_lane) {
+            const bool is_rvo = C.valid && C.active && !(A.st & CAGYM_FLAG_DONE) && ST_POLICY(A.st) == CAGYM_POL_RVO;
+            bool need3 = false;
+            if (is_rvo) {
+                const OrcaEgo E = orca_ego(A, D.dt);
+                const int nn = (C.n - 1) < CAGYM_MAXNB ? (C.n - 1) : CAGYM_MAXNB;
+                float nvx, nvy;
+                const int fail = orca_lp2(W.sorted, tid, nn, E.max_speed, E.pvx, E.pvy, false, nvx, nvy);
+                W.lpv[tid] = make_float2(nvx, nvy);
+                W.lpk[tid] = fail;
+                W.lpr[tid] = E.max_speed;
+                need3 = fail < nn;
+            }
+            const unsigned long long m = __ballot(need3);
+            if (tid == 0) W.lpmask[0] = m;
+        }
+        __syncthreads();
+        STAMP(8);
+        const unsigned long long fm = W.lpmask[0];
+        if (fm) {
+            const int cnt = __popcll(fm), g = tid >> 4, j = tid & 15;
+            for (int base = 0; base < cnt; base += NT / 16) {
+                int idx = base + g;
+                if (idx < cnt) {
+                    unsigned long long mm = fm;
+                    for (int s = 0; s < idx; s++) mm &= mm - 1ull;
+                    const int a = __ffsll((long long)mm) - 1;
+                    const int wl = (int)__umulhi((uint32_t)a, inv_m);
+                    const int n = W.wn[wl];
+                    const int nn = (n - 1) < CAGYM_MAXNB ? (n - 1) : CAGYM_MAXNB;
+                    float2 v = W.lpv[a];
+                    orca_lp3_group(W.sorted, W.proj, a, j, nn, W.lpk[a], W.lpr[a], v.x, v.y);
+                    if (j == 0) W.lpv[a] = v;
+                }
+            }
+            __syncthreads();
+        }
+        STAMP(9);
+    }
+    if (agent_lane) {
+        float a0 = 0.f, a1 = 0.f;
+        if (C.valid && C.active && !(A.st & CAGYM_FLAG_DONE)) {
+            double d0 = 0.0, d1 = 0.0;
+            switch (ST_POLICY(A.st)) {
+                case CAGYM_POL_STATIC: break;
+                case CAGYM_POL_NONCOOP: d0 = A.pref; d1 = -A.he; break;
+                case CAGYM_POL_EXTERNAL: case CAGYM_POL_IGMCTS: case CAGYM_POL_GA3C:
+                    if (ext) { d0 = (double)ext[2 * aidx]; d1 = (double)ext[2 * aidx + 1]; }
+                    break;
+                case CAGYM_POL_LEARNING:
+                    if (ext) { d1 = 4.0 * (2. * (double)ext[2 * aidx + 1] - 1.); d0 = A.pref * (double)ext[2 * aidx]; }
+                    else { d1 = -4.0; }
+                    break;
+                case CAGYM_POL_CARRL: d0 = 1.0; d1 = carrl_heading(ext ? (int)ext[2 * aidx] : 0); break;
+                case CAGYM_POL_RVO: {
+                    const float2 v = W.lpv[tid];
+                    orca_post(A, v.x, v.y, D.dt, d0, d1);
+                    break;
+                }
+            }
+            a0 = (float)d0;
+            a1 = (float)d1;
+        }
+        if (C.valid && C.active) take_action(A, a0, a1, D.dt);
+        publish_tile2(W, A, tid);  // nobody reads the tile here (P1 / LP3 readers are behind their barriers)
+    }
+    __syncthreads();  // post-move tile visible; LP scratch (union, pre-move view) is dead
+    STAMP(3);
+    // ---- P2: pair distances, collision tests (env.py:630-655), OAS sort keys ------------------------------
+    for (int p = tid; p < npairs; p += NT) {
+        const PairIdx q = pair_of(p, M, inv_m);
+        const int n = W.wn[q.wl];
+        const bool on = q.sl < n && q.j < n && q.j != q.sl;
+        double key = -INFINITY, gp = INFINITY;
+        uint8_t ht = 0;
+        if (on) {
+            const int b = q.a - q.sl + q.j;
+            const double dx = W.tpx[b] - W.tpx[q.a], dy = W.tpy[b] - W.tpy[q.a];
+            const double d = norm2(dx, dy);
+            const double ra = W.tr[q.a], rb = W.tr[b];
+            const bool static_hi = ST_POLICY(q.j > q.sl ? W.tst[b] : W.tst[q.a]) == CAGYM_POL_STATIC;
+            const bool skip = static_hi && !D.collide_static;  // env.py:643 (Q8)
+            const double cr = (q.j > q.sl) ? (ra + rb) : (rb + ra);
+            ht = (!skip && d <= cr) ? 1 : 0;
+            if (!skip && q.j > q.sl) gp = d - cr;  // lower index only (Q7)
+            key = d - ra - rb;
+        }
+        W.hit[q.a * MP + q.j] = ht;
+        W.gap[q.a * MP + q.j] = gp;
+        W.keys[q.a * MP + q.j] = key;
+        if (q.j == M - 1)
+            for (int l = M; l < MP; l++) {
+                W.hit[q.a * MP + l] = 0;
+                W.gap[q.a * MP + l] = INFINITY;
+                W.keys[q.a * MP + l] = -INFINITY;
+            }
+    }
+    __syncthreads();
+    STAMP(4);
+    // ---- S2: _compute_rewards (env.py:502-567), _check_which_agents_done (:711-738), auto-reset -----------
+    if (agent_lane) {
+        float reward = 0.f;
+        if (C.valid && C.active) {
+            bool coll_wall = false;
+            double dmin = INFINITY;
+            uint32_t hits = 0;
+            const uint32_t* hrow = reinterpret_cast<const uint32_t*>(W.hit + tid * MP);
+            const double2* grow = reinterpret_cast<const double2*>(W.gap + tid * MP);
+            for (int l4 = 0; l4 < MP; l4 += 4) {
+                hits |= hrow[l4 >> 2];
+                const double2 g0 = grow[l4 >> 1], g1 = grow[(l4 >> 1) + 1];
+                dmin = fmin(dmin, fmin(fmin(g0.x, g0.y), fmin(g1.x, g1.y)));
+            }
+            const bool coll_agent = hits != 0;
+            if (D.map_bits) {
+                int sidx = (int)(((long long)C.world + (long long)C.episode * D.N) % D.S);
+                if (D.sc_nobst[sidx] > 0)
+                    coll_wall = wall_collision(D.map_bits + (size_t)sidx * CAGYM_MAPD * CAGYM_MAPW, A.px, A.py, A.r);
+            }
+            double r = -0.01;
+            if (A.st & CAGYM_FLAG_AT_GOAL) {
+                if (!(A.st & CAGYM_FLAG_WAS_AT_GOAL)) r = 3.0;
+            } else {
+                if (!(A.st & CAGYM_FLAG_WAS_IN_COLLISION)) {
+                    if (coll_agent) { r = -10.0; A.st |= CAGYM_FLAG_IN_COLLISION; }
+                    else if (coll_wall) { r = -0.25; A.st |= CAGYM_FLAG_IN_COLLISION; }
+                    else if (dmin <= 0.2) r += -0.1 - dmin / 2.;
+                } else if (A.st & CAGYM_FLAG_RAN_OUT_OF_TIME) {
+                    r += -10.0;
+                }
+            }
+            r = clipd(r, -10.0, 3.0) / (3.0 - (-10.0));
+            reward = (float)r;
+            if (A.st & (CAGYM_FLAG_AT_GOAL | CAGYM_FLAG_RAN_OUT_OF_TIME | CAGYM_FLAG_IN_COLLISION)) A.st |= CAGYM_FLAG_DONE;
+        }
+        const bool live = C.valid && C.active;
+        const bool done = !live || (A.st & CAGYM_FLAG_DONE);
+        const uint64_t wm = world_mask64(C);
+        const uint64_t b_done = __ballot(done);
+        const uint64_t b_learn = __ballot(done || ST_POLICY(A.st) != CAGYM_POL_LEARNING);
+        bool go;
+        if (D.go_mode == CAGYM_GO_ALL) go = (b_done & wm) == wm;
+        else if (D.go_mode == CAGYM_GO_LEARNING) go = (b_learn & wm) == wm;
+        else go = C.n > 0 ? ((b_done >> C.base) & 1ull) : true;
+        if (C.valid) {
+            if (out.reward) out.reward[aidx] = reward;
+            if (out.flags) out.flags[aidx] = (uint8_t)(A.st & 0xffu);
+            if (C.slot == 0) {
+                if (out.game_over) out.game_over[C.world] = go ? 1 : 0;
+                ep_ret += reward;
+                ep_len += 1;
+            }
+        }
+        bool any_reset = false;
+        if (AUTO_RESET) {
+            const bool rs = C.valid && go;
+            any_reset = __ballot(rs) != 0ull;
+            if (any_reset) {
+                float r0 = rs ? ep_ret : 0.f;
+                int l0 = rs ? ep_len : 0;
+                LaneCtx Cr = C;
+                Cr.valid = rs;
+                fold_episode_stats(D, Cr, A, r0, l0);
+                if (rs) {
+                    ep_ret = 0.f;
+                    ep_len = 0;
+                    C.episode += 1;
+                    int sidx = (int)(((long long)C.world + (long long)C.episode * D.N) % D.S);
+                    C.n = D.sc_nagents[sidx];
+                    C.active = C.slot < C.n;
+                    init_agent(D, A, sidx, C.slot, C.active);
+                }
+                publish_tile2(W, A, tid);
+                if (C.valid && C.slot == 0) W.wn[C.wl] = C.n;
+            }
+        }
+        if (tid == 0) W.flag[0] = any_reset ? 1 : 0;
+        // reference axes of every agent for the OAS projection (agent.py:250-269)
+        W.tprx[tid] = (C.valid && C.active) ? A.prx : 0.0;
+        W.tpry[tid] = (C.valid && C.active) ? A.pry : 0.0;
+    }
+    __syncthreads();
+    STAMP(5);
+    // ---- P3: OtherAgentsStatesSensor rows (sensors/OtherAgentsStatesSensor.py:11-77) ----------------------
+    if (AUTO_RESET && W.flag[0]) {  // rare: some world restarted -> sort keys of the new episode
+        for (int p = tid; p < npairs; p += NT) {
+            const PairIdx q = pair_of(p, M, inv_m);
+            const int n = W.wn[q.wl];
+            double key = -INFINITY;
+            if (q.sl < n && q.j < n && q.j != q.sl) {
+                const int b = q.a - q.sl + q.j;
+                key = norm2(W.tpx[b] - W.tpx[q.a], W.tpy[b] - W.tpy[q.a]) - W.tr[q.a] - W.tr[b];
+            }
+            W.keys[q.a * MP + q.j] = key;
+        }
+        __syncthreads();
+    }
+    for (int p = tid; p < npairs; p += NT) {
+        const PairIdx q = pair_of(p, M, inv_m);
+        if (q.j == q.sl) continue;
+        const int n = W.wn[q.wl];
+        float* my = W.oas + (size_t)q.a * K * 10;
+        const double kj = W.keys[q.a * MP + q.j];
+        float v[10];
+        int row;
+        if (!(kj > -INFINITY)) {  // unused row: zero (rows n-1 .. K-1 of an active agent, every row of an empty slot)
+            row = q.sl < n ? q.j - 1 : (q.j < q.sl ? q.j : q.j - 1);
+#pragma unroll
+            for (int c = 0; c < 10; c++) v[c] = 0.f;
+        } else {
+            int before = 0;  // descending key, ties by descending index (stable sort, reversed: :28-34)
+            const double2* krow = reinterpret_cast<const double2*>(W.keys + q.a * MP);
+            for (int l2 = 0; l2 < MP; l2 += 2) {
+                const double2 kk = krow[l2 >> 1];
+                before += (kk.x > kj) || (kk.x == kj && l2 + 0 > q.j);
+                before += (kk.y > kj) || (kk.y == kj && l2 + 1 > q.j);
+            }
+            row = before;
+            const int b = q.a - q.sl + q.j;
+            const double dx = W.tpx[b] - W.tpx[q.a], dy = W.tpy[b] - W.tpy[q.a];
+            const double prx = W.tprx[q.a], pry = W.tpry[q.a], orx = -pry, ory = prx;
+            const double ovx = W.tvx[b], ovy = W.tvy[b], orad = W.tr[b];
+            v[0] = (float)dx;
+            v[1] = (float)dy;
+            v[2] = (float)dot2(dx, dy, prx, pry);
+            v[3] = (float)dot2(dx, dy, orx, ory);
+            v[4] = (float)dot2(ovx, ovy, prx, pry);
+            v[5] = (float)dot2(ovx, ovy, orx, ory);
+            v[6] = (float)orad;
+            v[7] = (float)(W.tr[q.a] + orad);
+            v[8] = (float)kj;
+            v[9] = ST_POLICY(W.tst[b]) == CAGYM_POL_STATIC ? 1.f : 2.f;
+        }
+        float2* r2 = reinterpret_cast<float2*>(my + row * 10);  // rows are 40 B: 8-byte aligned
+#pragma unroll
+        for (int c = 0; c < 5; c++) r2[c] = make_float2(v[2 * c], v[2 * c + 1]);
+    }
+    __syncthreads();
+    STAMP(6);
+    // ---- store: the staged OAS table as contiguous 16-B lanes, ego observation from the agent lanes --------
+    if (out.obs_oas) {
+        const size_t world0 = (size_t)blockIdx.x * C.wpw;
+        const int per_world4 = M * K * 10 / 4;
+        const float4* src = reinterpret_cast<const float4*>(W.oas);
+        float4* dst = reinterpret_cast<float4*>(out.obs_oas) + world0 * per_world4;
+        const int total4 = C.worlds_valid * per_world4;
+        for (int q = tid; q < total4; q += NT) dst[q] = src[q];
+    }
+    if (agent_lane && C.valid) {
+        const int nobs = C.active ? C.n - 1 : 0;
+        D.n_observed[aidx] = nobs;
+        if (out.obs_ego) {
+            float4* e = reinterpret_cast<float4*>(out.obs_ego + aidx * CAGYM_EGO_WIDTH);
+            if (C.active) {
+                e[0] = make_float4((float)A.dg, (float)(A.gx - A.px), (float)(A.gy - A.py), (float)A.r);
+                e[1] = make_float4((float)A.he, (float)A.h, (float)A.px, (float)A.py);
+                e[2] = make_float4((float)A.pref, (float)nobs, ST_POLICY(A.st) == CAGYM_POL_LEARNING ? 1.f : 0.f, 0.f);
+            } else {
+                e[0] = e[1] = e[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    }
+    STAMP(7);
+    // the next S0 barrier orders these staging reads before the union is rewritten
+}
+
+template <int NT, bool AUTO_RESET>
+__global__ void __launch_bounds__(NT, (NT <= 256 ? 3 : 2)) k_rollout2(CagymDev D, int n_steps, CagymOut out, int any_rvo) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    Lds2 W = carve_lds2(smem, D.M);
+    LaneCtx C = make_ctx(D);
+    Agent A = {};
+    const bool agent_lane = threadIdx.x < CAGYM_WAVE;
+    const size_t aidx = (size_t)C.world * D.M + C.slot;
+    float ep_ret = 0.f;
+    int ep_len = 0;
+    if (!agent_lane) C.valid = C.active = false;
+    if (C.valid) {
+        load_agent(D, A, aidx);
+        if (C.slot == 0) { ep_ret = D.ep_return[C.world]; ep_len = D.ep_len[C.world]; }
+    }
+    const size_t NM = (size_t)D.N * D.M;
+    for (int t = 0; t < n_steps; t++) {
+        CagymOut o;
+        o.obs_oas = out.obs_oas ? out.obs_oas + (size_t)t * NM * (D.M - 1) * 10 : nullptr;
+        o.obs_ego = out.obs_ego ? out.obs_ego + (size_t)t * NM * CAGYM_EGO_WIDTH : nullptr;
+        o.laserscan = nullptr;
+        o.reward = out.reward ? out.reward + (size_t)t * NM : nullptr;
+        o.flags = out.flags ? out.flags + (size_t)t * NM : nullptr;
+        o.game_over = out.game_over ? out.game_over + (size_t)t * D.N : nullptr;
+        step_core2<NT, AUTO_RESET>(D, W, C, A, nullptr, o, ep_ret, ep_len, any_rvo != 0);
+    }
+    if (C.valid) {
+        store_agent(D, A, aidx, true);
+        if (C.slot == 0) {
+            D.ep_return[C.world] = ep_ret;
+            D.ep_len[C.world] = ep_len;
+            D.episode[C.world] = C.episode;
+            D.n_agents[C.world] = C.n;
+        }
+    }
+}
+
+template <int NT>
+__global__ void __launch_bounds__(NT) k_step2(CagymDev D, const float* ext, CagymOut out, int any_rvo) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    Lds2 W = carve_lds2(smem, D.M);
+    LaneCtx C = make_ctx(D);
+    Agent A = {};
+    const bool agent_lane = threadIdx.x < CAGYM_WAVE;
+    const size_t aidx = (size_t)C.world * D.M + C.slot;
+    float ep_ret = 0.f;
+    int ep_len = 0;
+    if (!agent_lane) C.valid = C.active = false;
+    if (C.valid) {
+        load_agent(D, A, aidx);
+        if (C.slot == 0) { ep_ret = D.ep_return[C.world]; ep_len = D.ep_len[C.world]; }
+    }
+    step_core2<NT, false>(D, W, C, A, ext, out, ep_ret, ep_len, any_rvo != 0);
+    if (C.valid) {
+        store_agent(D, A, aidx, false);
+        if (C.slot == 0) { D.ep_return[C.world] = ep_ret; D.ep_len[C.world] = ep_len; }
+    }
+}

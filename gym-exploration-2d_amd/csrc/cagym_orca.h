@@ -122,92 +122,88 @@ struct NbrTile {
     double* r;
 };
 
-// RVOPolicy.find_next_action for the agent on `lane`; base = first lane of its world, n = agents in
-// the world, i = own slot.  L, P: LDS line arrays [CAGYM_MAXNB][64].  Returns (speed, delta_heading).
-__device__ inline void orca_action(const NbrTile& T, float4* L, float4* P, int lane, int base, int n, int i,
-                                   const Agent& A, double dt, double& out_speed, double& out_dh) {
-    const float pex = (float)A.px, pey = (float)A.py, vex = (float)A.vx, vey = (float)A.vy;
-    const float re = (float)((1 + 15e-2) * A.r);
+// fp32 view of the ego used by every half-plane of one solve (RVOPolicy.py:65-85)
+struct OrcaEgo {
+    float px, py, vx, vy, r, pvx, pvy, max_speed, time_step, c;
+};
+
+__device__ __forceinline__ OrcaEgo orca_ego(const Agent& A, double dt) {
+    OrcaEgo E;
+    E.px = (float)A.px; E.py = (float)A.py; E.vx = (float)A.vx; E.vy = (float)A.vy;
+    E.r = (float)((1 + 15e-2) * A.r);
     double gx = A.gx - A.px, gy = A.gy - A.py;
     double sc = A.pref / norm2(gx, gy);
-    const float pvx = (float)(sc * gx), pvy = (float)(sc * gy);
-    const float max_speed = (float)A.pref;
-    const float time_step = (float)dt, inv_th = 1.0f / 5.0f;
-    const float c = (float)A.coop;
+    E.pvx = (float)(sc * gx); E.pvy = (float)(sc * gy);
+    E.max_speed = (float)A.pref;
+    E.time_step = (float)dt;
+    E.c = (float)A.coop;
+    return E;
+}
 
-    // neighbour selection: nearest first, ties in index order, at most 10 (Agent::insertAgentNeighbor).
-    // rank by counting == the insertion sort's result; ranks >= 10 are dropped.
-    int nn = (n - 1) < CAGYM_MAXNB ? (n - 1) : CAGYM_MAXNB;
-    for (int j = 0; j < n; j++) {
-        if (j == i) continue;
-        float ox = (float)T.px[base + j], oy = (float)T.py[base + j];
-        float dx = pex - ox, dy = pey - oy;
-        float dsq = dx * dx + dy * dy;
-        int rank = 0;
-        for (int l = 0; l < n; l++) {
-            if (l == i || l == j) continue;
-            float qx = pex - (float)T.px[base + l], qy = pey - (float)T.py[base + l];
-            float qsq = qx * qx + qy * qy;
-            rank += (qsq < dsq) || (qsq == dsq && l < j);
-        }
-        if (rank >= CAGYM_MAXNB) continue;
-        float rpx = ox - pex, rpy = oy - pey;
-        float rvx = vex - (float)T.vx[base + j], rvy = vey - (float)T.vy[base + j];
-        float ro = (float)((1 + 15e-2) * T.r[base + j]);
-        float d2 = rpx * rpx + rpy * rpy;
-        float cr = re + ro, crsq = cr * cr;
-        float ux, uy;
-        float4 ln;
-        if (d2 > crsq) {
-            float wx = rvx - inv_th * rpx, wy = rvy - inv_th * rpy;
-            float wlsq = wx * wx + wy * wy;
-            float dp1 = wx * rpx + wy * rpy;
-            if (dp1 < 0.0f && dp1 * dp1 > crsq * wlsq) {
-                float wl = sqrtf(wlsq);
-                float inv = 1.0f / wl;
-                float uwx = wx * inv, uwy = wy * inv;
-                ln.z = uwy;
-                ln.w = -uwx;
-                float s = cr * inv_th - wl;
-                ux = s * uwx;
-                uy = s * uwy;
-            } else {
-                float leg = sqrtf(d2 - crsq);
-                float inv = 1.0f / d2;
-                if (detf(rpx, rpy, wx, wy) > 0.0f) {
-                    ln.z = (rpx * leg - rpy * cr) * inv;
-                    ln.w = (rpx * cr + rpy * leg) * inv;
-                } else {
-                    ln.z = -((rpx * leg + rpy * cr) * inv);
-                    ln.w = -((-rpx * cr + rpy * leg) * inv);
-                }
-                float dp2 = rvx * ln.z + rvy * ln.w;
-                ux = dp2 * ln.z - rvx;
-                uy = dp2 * ln.w - rvy;
-            }
-        } else {
-            float inv_ts = 1.0f / time_step;
-            float wx = rvx - inv_ts * rpx, wy = rvy - inv_ts * rpy;
-            float wl = sqrtf(wx * wx + wy * wy);
+// One ORCA half-plane ego <- other (Agent::computeNewVelocity body), other given in fp64 as stored.
+__device__ __forceinline__ float4 orca_line(float pex, float pey, float vex, float vey, float re, float c,
+                                            float time_step, double opx, double opy, double ovx, double ovy, double orad) {
+    const float inv_th = 1.0f / 5.0f;
+    float ox = (float)opx, oy = (float)opy;
+    float rpx = ox - pex, rpy = oy - pey;
+    float rvx = vex - (float)ovx, rvy = vey - (float)ovy;
+    float ro = (float)((1 + 15e-2) * orad);
+    float d2 = rpx * rpx + rpy * rpy;
+    float cr = re + ro, crsq = cr * cr;
+    float ux, uy;
+    float4 ln;
+    if (d2 > crsq) {
+        float wx = rvx - inv_th * rpx, wy = rvy - inv_th * rpy;
+        float wlsq = wx * wx + wy * wy;
+        float dp1 = wx * rpx + wy * rpy;
+        if (dp1 < 0.0f && dp1 * dp1 > crsq * wlsq) {
+            float wl = sqrtf(wlsq);
             float inv = 1.0f / wl;
             float uwx = wx * inv, uwy = wy * inv;
             ln.z = uwy;
             ln.w = -uwx;
-            float s = cr * inv_ts - wl;
+            float s = cr * inv_th - wl;
             ux = s * uwx;
             uy = s * uwy;
+        } else {
+            float leg = sqrtf(d2 - crsq);
+            float inv = 1.0f / d2;
+            if (detf(rpx, rpy, wx, wy) > 0.0f) {
+                ln.z = (rpx * leg - rpy * cr) * inv;
+                ln.w = (rpx * cr + rpy * leg) * inv;
+            } else {
+                ln.z = -((rpx * leg + rpy * cr) * inv);
+                ln.w = -((-rpx * cr + rpy * leg) * inv);
+            }
+            float dp2 = rvx * ln.z + rvy * ln.w;
+            ux = dp2 * ln.z - rvx;
+            uy = dp2 * ln.w - rvy;
         }
-        ln.x = vex + c * ux;
-        ln.y = vey + c * uy;
-        L[rank * CAGYM_WAVE + lane] = ln;
+    } else {
+        float inv_ts = 1.0f / time_step;
+        float wx = rvx - inv_ts * rpx, wy = rvy - inv_ts * rpy;
+        float wl = sqrtf(wx * wx + wy * wy);
+        float inv = 1.0f / wl;
+        float uwx = wx * inv, uwy = wy * inv;
+        ln.z = uwy;
+        ln.w = -uwx;
+        float s = cr * inv_ts - wl;
+        ux = s * uwx;
+        uy = s * uwy;
     }
-    float nvx, nvy;
-    int fail = orca_lp2(L, lane, nn, max_speed, pvx, pvy, false, nvx, nvy);
-    if (fail < nn) orca_lp3(L, P, lane, nn, fail, max_speed, nvx, nvy);
-    float npx = pex + nvx * time_step, npy = pey + nvy * time_step;  // Agent::update, fp32
-    double dpx = (double)npx - A.px, dpy = (double)npy - A.py;       // RVOPolicy.py:91-106, fp64
+    ln.x = vex + c * ux;
+    ln.y = vey + c * uy;
+    return ln;
+}
+
+// Agent::update (fp32) and the fp64 tail of RVOPolicy.find_next_action (RVOPolicy.py:91-106).
+__device__ inline void orca_post(const Agent& A, float nvx, float nvy, double dt, double& out_speed, double& out_dh) {
+    const float time_step = (float)dt;
+    float npx = (float)A.px + nvx * time_step, npy = (float)A.py + nvy * time_step;  // Agent::update, fp32
+    double dpx = (double)npx - A.px, dpy = (double)npy - A.py;                      // back in Python, fp64
     double ang1 = atan2(dpy, dpx);
-    double nh = fmod(ang1, 2 * kPi);
+    /* (ang1 - 0) % (2*pi), Python float modulo; |ang1| <= pi so fmod(ang1, 2*pi) == ang1 exactly */
+    double nh = ang1;
     if (nh < 0) nh += 2 * kPi;
     double dh = wrap_angle(nh - A.h);
     double speed = 1 / dt * norm2(dpx, dpy);
@@ -217,4 +213,130 @@ __device__ inline void orca_action(const NbrTile& T, float4* L, float4* P, int l
     }
     out_speed = speed;
     out_dh = dh;
+}
+
+// LP2 (+LP3) on the nn sorted lines of `lane`, then Agent::update and RVOPolicy.py:91-106.
+__device__ inline void orca_solve(const float4* L, float4* P, int lane, int nn, const OrcaEgo& E, const Agent& A,
+                                  double dt, double& out_speed, double& out_dh) {
+    float nvx, nvy;
+    int fail = orca_lp2(L, lane, nn, E.max_speed, E.pvx, E.pvy, false, nvx, nvy);
+    if (fail < nn) orca_lp3(L, P, lane, nn, fail, E.max_speed, nvx, nvy);
+    orca_post(A, nvx, nvy, dt, out_speed, out_dh);
+}
+
+// RVOPolicy.find_next_action for the agent on `lane`; base = first lane of its world, n = agents in
+// the world, i = own slot.  L, P: LDS line arrays [CAGYM_MAXNB][64].  Returns (speed, delta_heading).
+__device__ inline void orca_action(const NbrTile& T, float4* L, float4* P, int lane, int base, int n, int i,
+                                   const Agent& A, double dt, double& out_speed, double& out_dh) {
+    const OrcaEgo E = orca_ego(A, dt);
+    // neighbour selection: nearest first, ties in index order, at most 10 (Agent::insertAgentNeighbor).
+    // rank by counting == the insertion sort's result; ranks >= 10 are dropped.
+    int nn = (n - 1) < CAGYM_MAXNB ? (n - 1) : CAGYM_MAXNB;
+    for (int j = 0; j < n; j++) {
+        if (j == i) continue;
+        float ox = (float)T.px[base + j], oy = (float)T.py[base + j];
+        float dx = E.px - ox, dy = E.py - oy;
+        float dsq = dx * dx + dy * dy;
+        int rank = 0;
+        for (int l = 0; l < n; l++) {
+            if (l == i || l == j) continue;
+            float qx = E.px - (float)T.px[base + l], qy = E.py - (float)T.py[base + l];
+            float qsq = qx * qx + qy * qy;
+            rank += (qsq < dsq) || (qsq == dsq && l < j);
+        }
+        if (rank >= CAGYM_MAXNB) continue;
+        L[rank * CAGYM_WAVE + lane] = orca_line(E.px, E.py, E.vx, E.vy, E.r, E.c, E.time_step, T.px[base + j],
+                                                T.py[base + j], T.vx[base + j], T.vy[base + j], T.r[base + j]);
+    }
+    orca_solve(L, P, lane, nn, E, A, dt, out_speed, out_dh);
+}
+
+// ---- cooperative linearProgram3 --------------------------------------------------------------------
+// One ego per 16-lane group, lane j <-> half-plane j.  Same arithmetic as orca_lp3/orca_lp2/orca_lp1 above:
+// the interval clipping of linearProgram1 (tLeft = max, tRight = min, "parallel and outside" / tLeft > tRight
+// failures) does not depend on the order in which the earlier lines are visited, so it is a 16-lane
+// min/max/any reduction; the outer loops over i (violated line) and k (projected line) stay sequential.
+// All 16 lanes of a group run the same control flow; groups of one wave may diverge from each other.
+__device__ __forceinline__ float grp16_max(float v) {
+    v = fmaxf(v, __shfl_xor(v, 8, 16));
+    v = fmaxf(v, __shfl_xor(v, 4, 16));
+    v = fmaxf(v, __shfl_xor(v, 2, 16));
+    return fmaxf(v, __shfl_xor(v, 1, 16));
+}
+__device__ __forceinline__ float grp16_min(float v) {
+    v = fminf(v, __shfl_xor(v, 8, 16));
+    v = fminf(v, __shfl_xor(v, 4, 16));
+    v = fminf(v, __shfl_xor(v, 2, 16));
+    return fminf(v, __shfl_xor(v, 1, 16));
+}
+
+__device__ inline void orca_lp3_group(const float4* L, float4* P, int a, int j, int nn, int begin, float radius,
+                                      float& rx, float& ry) {
+    const int gbase = (threadIdx.x & 63) & ~15;
+    float distance = 0.0f;
+    for (int i = begin; i < nn; i++) {
+        const float4 li = L[i * CAGYM_WAVE + a];
+        if (!(detf(li.z, li.w, li.x - rx, li.y - ry) > distance)) continue;
+        // projected line of lane j (j < i); `have` = it exists (not "parallel, same direction")
+        bool have = false;
+        float4 pj = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (j < i) {
+            const float4 lj = L[j * CAGYM_WAVE + a];
+            const float d = detf(li.z, li.w, lj.z, lj.w);
+            have = true;
+            if (fabsf(d) <= RVO_EPS) {
+                if (li.z * lj.z + li.w * lj.w > 0.0f) have = false;
+                pj.x = 0.5f * (li.x + lj.x);
+                pj.y = 0.5f * (li.y + lj.y);
+            } else {
+                const float s = detf(lj.z, lj.w, li.x - lj.x, li.y - lj.y) / d;
+                pj.x = li.x + s * li.z;
+                pj.y = li.y + s * li.w;
+            }
+            const float ddx = lj.z - li.z, ddy = lj.w - li.w;
+            const float inv = 1.0f / sqrtf(ddx * ddx + ddy * ddy);
+            pj.z = ddx * inv;
+            pj.w = ddy * inv;
+            if (have) P[j * CAGYM_WAVE + a] = pj;
+        }
+        const uint32_t hmask = (uint32_t)((__ballot(have) >> gbase) & 0xffffull);
+        const float ox = -li.w, oy = li.z;
+        const float tx = rx, ty = ry;
+        float qx = ox * radius, qy = oy * radius;  // linearProgram2, directionOpt
+        bool failed = false;
+        for (int k = 0; k < i && !failed; k++) {
+            if (!((hmask >> k) & 1u)) continue;
+            const float4 pk = P[k * CAGYM_WAVE + a];
+            if (!(detf(pk.z, pk.w, pk.x - qx, pk.y - qy) > 0.0f)) continue;
+            // linearProgram1(k), directionOpt
+            const float dot = pk.x * pk.z + pk.y * pk.w;
+            const float disc = dot * dot + radius * radius - (pk.x * pk.x + pk.y * pk.y);
+            if (disc < 0.0f) { failed = true; break; }
+            const float sq = sqrtf(disc);
+            float tl = -dot - sq, tr = -dot + sq;
+            float ltl = -INFINITY, ltr = INFINITY;
+            bool lfail = false;
+            if (j < k && have) {
+                const float den = detf(pk.z, pk.w, pj.z, pj.w);
+                const float num = detf(pj.z, pj.w, pk.x - pj.x, pk.y - pj.y);
+                if (fabsf(den) <= RVO_EPS) {
+                    if (num < 0.0f) lfail = true;
+                } else {
+                    const float t = num / den;
+                    if (den >= 0.0f) ltr = t;
+                    else ltl = t;
+                }
+            }
+            tl = fmaxf(tl, grp16_max(ltl));
+            tr = fminf(tr, grp16_min(ltr));
+            const bool anyfail = ((__ballot(lfail) >> gbase) & 0xffffull) != 0ull;
+            if (anyfail || tl > tr) { failed = true; break; }
+            const float t = (ox * pk.z + oy * pk.w > 0.0f) ? tr : tl;
+            qx = pk.x + t * pk.z;
+            qy = pk.y + t * pk.w;
+        }
+        if (failed) { rx = tx; ry = ty; }
+        else { rx = qx; ry = qy; }
+        distance = detf(li.z, li.w, li.x - rx, li.y - ry);
+    }
 }

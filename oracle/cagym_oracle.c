@@ -498,8 +498,9 @@ void cao_orca_action(int M, int ego, const double* pos, const double* vel, const
     /* back in Python, fp64 (RVOPolicy.py:91-106) */
     double dpx = (double)npx - pos[2 * ego], dpy = (double)npy - pos[2 * ego + 1];
     double ang1 = atan2(dpy, dpx);
-    double nh = fmod(ang1, 2 * PI);
-    if (nh < 0) nh += 2 * PI; /* Python float modulo: result has the divisor's sign */
+    /* (ang1 - 0) % (2*pi), Python float modulo; |ang1| <= pi so fmod(ang1, 2*pi) == ang1 exactly */
+    double nh = ang1;
+    if (nh < 0) nh += 2 * PI;
     double dh = wrap(nh - heading);
     double speed = 1 / dt * norm2(dpx, dpy);
     if (fabs(dh) > PI / 6) {

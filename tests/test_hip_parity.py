@@ -177,3 +177,35 @@ def test_full_size_properties():
     ep = int(st["stat_episodes"].sum())
     out = st["stat_outcomes"].sum(0)
     assert ep > 0 and int(out[0]) > 10 * int(out[1])
+
+
+@pytest.mark.parametrize("M", [4, 10, 13, 20])
+def test_generation1_and_generation2_kernels_agree_bitwise(M, monkeypatch):
+    """The phase-split kernels (generation 2, default) share the arithmetic of the one-lane-per-agent
+    kernels (generation 1, CAGYM_KERNEL=v1): trajectories, observations and statistics must be identical."""
+    import torch
+    N, T = 50, 200
+    a6 = scen.random_worlds_fast(3 * N, M, seed=77 + M)
+    rng = np.random.default_rng(M)
+    pol = np.where(rng.uniform(size=(3 * N, M)) < 0.8, scen.POLICY_RVO, scen.POLICY_NONCOOP).astype(np.int32)
+    pol[rng.uniform(size=(3 * N, M)) < 0.05] = scen.POLICY_STATIC
+    n_agents = rng.integers(max(1, M - 3), M + 1, 3 * N).astype(np.int32)
+    res = []
+    for gen in ("v1", "v2"):
+        monkeypatch.setenv("CAGYM_KERNEL", gen)
+        e = _hip(N=N, M=M, game_over_mode=1, n_scenarios=3 * N)
+        e.set_scenario(a6, pol, scen.DYN_UNICYCLE, n_agents=n_agents, coop=np.full((3 * N, M), 0.5))
+        e.reset()
+        tr = e.env.rollout(T, auto_reset=True)
+        obs, rew, go, info = e.env.step()
+        torch.cuda.synchronize()
+        st = {k: v.clone() for k, v in e.env.state().items()}
+        res.append(({k: v.clone() for k, v in tr.items()}, st, e.env.obs_oas.clone(), rew.clone()))
+        e.env.close()
+    (t1, s1, o1, r1), (t2, s2, o2, r2) = res
+    for k in t1:
+        assert torch.equal(t1[k], t2[k]), k
+    for k in s1:
+        assert torch.equal(s1[k], s2[k]), k
+    assert torch.equal(o1, o2) and torch.equal(r1, r2)
+    assert int(s1["stat_episodes"].sum()) > 0

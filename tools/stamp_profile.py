@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Diagnostic: per-phase s_memtime shares of the phase-split step kernel (never the shipped library).
+Builds libcagym_hip_stamps.so with -DCAGYM_STAMPS, runs a rollout, prints cycles per step per phase."""
+import ctypes, importlib, os, subprocess, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+b = importlib.import_module("gym-exploration-2d_amd.build")
+import torch
+tl = os.path.join(os.path.dirname(torch.__file__), "lib")
+lib = os.path.join(b.CSRC, "libcagym_hip_stamps.so")
+obj = os.path.join(b.CSRC, "cagym_api_stamps.o")
+subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-c", "-DCAGYM_STAMPS"] + b.FLAGS + ["-o", obj, os.path.join(b.CSRC, "cagym_api.hip")])
+subprocess.check_call(["g++", "-shared", "-o", lib, obj, "-L" + tl, "-lamdhip64", "-Wl,-rpath," + tl])
+os.environ["CAGYM_LIB"] = lib
+scen = importlib.import_module("gym-exploration-2d_amd.scenarios")
+B = importlib.import_module("gym-exploration-2d_amd.batched_env").BatchedCollisionAvoidanceEnv
+pol = scen.POLICY_RVO if "noncoop" not in sys.argv else scen.POLICY_NONCOOP
+N, M, T = 4096, 10, 64
+env = B(N, M, n_scenarios=8 * N, game_over_mode="all")
+env.set_scenarios(scen.random_worlds_fast(8 * N, M), pol, scen.DYN_UNICYCLE, coop=np.full((8 * N, M), 0.5))
+env.reset()
+traj = env.alloc_rollout(T)
+for _ in range(4):
+    env.rollout(T, out=traj)
+torch.cuda.synchronize()
+out = (ctypes.c_ulonglong * 16)()
+env.L.cagym_debug_stamps(out, 1)
+R = 8
+for _ in range(R):
+    env.rollout(T, out=traj)
+torch.cuda.synchronize()
+env.L.cagym_debug_stamps(out, 0)
+names = ["S0 publish+bar", "P1a lines+bar", "P1b rank+bar", "S1c post+dynamics+bar", "P2 pairs+bar", "S2 reward/done+bar",
+         "P3 OAS rows+bar", "store", "S1a LP2 per agent+bar", "S1b coop LP3+bar"]
+tot = sum(out[:8]) + out[8] + out[9]
+print("s_memtime ticks (100 MHz constant clock?) per step, workgroup 0; total %.1f per step" % (tot / (R * T)))
+for i, n in enumerate(names[:10]):
+    print("  %-22s %10.1f  %5.1f %%" % (n, out[i] / (R * T), 100.0 * out[i] / tot))
