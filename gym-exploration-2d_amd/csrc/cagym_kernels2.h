@@ -33,9 +33,13 @@ __device__ unsigned long long g_stamps[16];
 #endif
 
 struct Lds2 {
-    double *tpx, *tpy, *tvx, *tvy, *tr, *tprx, *tpry;  // [64] agent tile
-    float* tcoop;                                        // [64]
-    uint32_t* tst;                                       // [64]
+    // [64] each: the agent record lives HERE between phases (registers only inside the S phases)
+    double *tpx, *tpy, *tvx, *tvy, *tr, *tprx, *tpry;
+    double *th, *the, *tdg, *ttrem, *tt, *tgx, *tgy, *tpref, *tspeed, *tdh, *taux0, *taux1, *tcoopd;
+    float2* tact;
+    float* tcoop;
+    uint32_t* tst;
+    int* tstep;
     int* wn;                                             // [32] agents per world of this workgroup
     int* flag;                                           // [4]  0: any world reset this step
     float2* lpv;                                         // [64] LP velocity of each agent (in/out of LP3)
@@ -60,7 +64,7 @@ __host__ __device__ inline int cagym_mp(int M) { return (M + 3) & ~3; }
 
 __host__ __device__ inline size_t cagym_lds2_bytes(int M) {
     const size_t MP = cagym_mp(M);
-    size_t head = 7 * 64 * 8 + 64 * 4 + 64 * 4 + 32 * 4 + 16 + 64 * 8 + 64 * 4 + 64 * 4 + 16;
+    size_t head = 20 * 64 * 8 + 64 * 8 + 64 * 4 + 64 * 4 + 64 * 4 + 32 * 4 + 16 + 64 * 8 + 64 * 4 + 64 * 4 + 16;
     size_t pre = 64 * MP * 4 + 64 * MP * 16 + 2 * (size_t)CAGYM_MAXNB * 64 * 16;
     size_t post = 2 * 64 * MP * 8 + 64 * MP + (size_t)64 * (M - 1) * 40;
     return a16(head) + (pre > post ? pre : post);
@@ -71,15 +75,20 @@ __device__ __forceinline__ Lds2 carve_lds2(unsigned char* smem, int M) {
     const size_t MP = cagym_mp(M);
     W.tpx = reinterpret_cast<double*>(smem);
     W.tpy = W.tpx + 64; W.tvx = W.tpy + 64; W.tvy = W.tvx + 64; W.tr = W.tvy + 64; W.tprx = W.tr + 64; W.tpry = W.tprx + 64;
-    W.tcoop = reinterpret_cast<float*>(W.tpry + 64);
+    W.th = W.tpry + 64; W.the = W.th + 64; W.tdg = W.the + 64; W.ttrem = W.tdg + 64; W.tt = W.ttrem + 64;
+    W.tgx = W.tt + 64; W.tgy = W.tgx + 64; W.tpref = W.tgy + 64; W.tspeed = W.tpref + 64; W.tdh = W.tspeed + 64;
+    W.taux0 = W.tdh + 64; W.taux1 = W.taux0 + 64; W.tcoopd = W.taux1 + 64;
+    W.tact = reinterpret_cast<float2*>(W.tcoopd + 64);
+    W.tcoop = reinterpret_cast<float*>(W.tact + 64);
     W.tst = reinterpret_cast<uint32_t*>(W.tcoop + 64);
-    W.wn = reinterpret_cast<int*>(W.tst + 64);
+    W.tstep = reinterpret_cast<int*>(W.tst + 64);
+    W.wn = W.tstep + 64;
     W.flag = W.wn + 32;
     W.lpv = reinterpret_cast<float2*>(W.flag + 4);
     W.lpk = reinterpret_cast<int*>(W.lpv + 64);
     W.lpr = reinterpret_cast<float*>(W.lpk + 64);
     W.lpmask = reinterpret_cast<unsigned long long*>(W.lpr + 64);
-    size_t head = 7 * 64 * 8 + 64 * 4 + 64 * 4 + 32 * 4 + 16 + 64 * 8 + 64 * 4 + 64 * 4 + 16;
+    size_t head = 20 * 64 * 8 + 64 * 8 + 64 * 4 + 64 * 4 + 64 * 4 + 32 * 4 + 16 + 64 * 8 + 64 * 4 + 64 * 4 + 16;
     unsigned char* u = smem + a16(head);
     W.dsq = reinterpret_cast<float*>(u);
     W.lines = reinterpret_cast<float4*>(u + 64 * MP * 4);
@@ -92,10 +101,34 @@ __device__ __forceinline__ Lds2 carve_lds2(unsigned char* smem, int M) {
     return W;
 }
 
-__device__ __forceinline__ void publish_tile2(const Lds2& W, const Agent& A, int lane) {
-    W.tpx[lane] = A.px; W.tpy[lane] = A.py; W.tvx[lane] = A.vx; W.tvy[lane] = A.vy; W.tr[lane] = A.r;
-    W.tcoop[lane] = (float)A.coop;
+// fields that change when an agent moves
+__device__ __forceinline__ void lds_store_moved(const Lds2& W, const Agent& A, int lane) {
+    W.tpx[lane] = A.px; W.tpy[lane] = A.py; W.tvx[lane] = A.vx; W.tvy[lane] = A.vy;
+    W.tprx[lane] = A.prx; W.tpry[lane] = A.pry;
+    W.th[lane] = A.h; W.the[lane] = A.he; W.tdg[lane] = A.dg; W.ttrem[lane] = A.trem; W.tt[lane] = A.t;
+    W.tspeed[lane] = A.speed; W.tdh[lane] = A.dh; W.taux0[lane] = A.aux0; W.taux1[lane] = A.aux1;
+    W.tact[lane] = make_float2(A.a0, A.a1);
     W.tst[lane] = A.st;
+    W.tstep[lane] = A.step;
+}
+__device__ __forceinline__ void lds_store_agent(const Lds2& W, const Agent& A, int lane) {
+    lds_store_moved(W, A, lane);
+    W.tr[lane] = A.r; W.tgx[lane] = A.gx; W.tgy[lane] = A.gy; W.tpref[lane] = A.pref;
+    W.tcoopd[lane] = A.coop;
+    W.tcoop[lane] = (float)A.coop;
+}
+__device__ __forceinline__ Agent lds_load_agent(const Lds2& W, int lane) {
+    Agent A;
+    A.px = W.tpx[lane]; A.py = W.tpy[lane]; A.vx = W.tvx[lane]; A.vy = W.tvy[lane]; A.r = W.tr[lane];
+    A.prx = W.tprx[lane]; A.pry = W.tpry[lane];
+    A.h = W.th[lane]; A.he = W.the[lane]; A.dg = W.tdg[lane]; A.trem = W.ttrem[lane]; A.t = W.tt[lane];
+    A.gx = W.tgx[lane]; A.gy = W.tgy[lane]; A.pref = W.tpref[lane]; A.speed = W.tspeed[lane]; A.dh = W.tdh[lane];
+    A.aux0 = W.taux0[lane]; A.aux1 = W.taux1[lane]; A.coop = W.tcoopd[lane];
+    const float2 a = W.tact[lane];
+    A.a0 = a.x; A.a1 = a.y;
+    A.st = W.tst[lane];
+    A.step = W.tstep[lane];
+    return A;
 }
 
 // pair slot p = agent * M + j  ->  (agent lane a, neighbour slot j, world_local wl, agent slot sl)
@@ -114,19 +147,19 @@ __device__ __forceinline__ PairIdx pair_of(int p, int M, uint32_t inv_m) {
 // One env.step() of the workgroup's worlds.  Agent registers A live on wave 0 (tid < 64) only; the pair
 // phases keep nothing in registers across barriers (everything is re-read from LDS).
 template <int NT, bool AUTO_RESET>
-__device__ inline void step_core2(const CagymDev& D, const Lds2& W, LaneCtx& C, Agent& A, const float* ext,
-                                  const CagymOut& out, float& ep_ret, int& ep_len, bool any_rvo) {
-    const int tid = threadIdx.x, M = D.M, K = M - 1, MP = cagym_mp(M);
+__device__ inline void step_core2(const CagymDev& D, const Lds2& W, LaneCtx& C, const float* ext, const CagymOut& out,
+                                  float& ep_ret, int& ep_len, bool any_rvo) {
+    int tid = threadIdx.x;
+    // opaque per step: keeps the compiler from hoisting every (agent, neighbour) index derived from tid out of
+    // the rollout's step loop (that hoisting cost ~100 VGPRs and spilled; recomputing is a few ALU ops)
+    asm volatile("" : "+v"(tid));
+    const int M = D.M, K = M - 1, MP = cagym_mp(M);
     const uint32_t inv_m = (uint32_t)(0x100000000ull / (uint32_t)M) + 1u;
     const bool agent_lane = tid < CAGYM_WAVE;
     const size_t aidx = (size_t)C.world * M + C.slot;
     const int npairs = C.wpw * M * M;
     STAMP_BEGIN();
-    // ---- S0: publish the pre-move tile ---------------------------------------------------------------
-    if (agent_lane) {
-        publish_tile2(W, A, tid);
-        if (C.wl < C.wpw && C.slot == 0) W.wn[C.wl] = C.valid ? C.n : 0;
-    }
+    // ---- S0: the previous step's staging reads are done before the union is rewritten ------------------
     __syncthreads();
     STAMP(0);
     // ---- P1: ORCA half-planes, one lane per (ego, neighbour) -------------------------------------------
@@ -175,13 +208,15 @@ __device__ inline void step_core2(const CagymDev& D, const Lds2& W, LaneCtx& C, 
     //      linearProgram3 of the infeasible agents cooperatively on 16-lane groups of every wave ------------
     if (any_rvo) {
         if (agent_lane) {
-            const bool is_rvo = C.valid && C.active && !(A.st & CAGYM_FLAG_DONE) && ST_POLICY(A.st) == CAGYM_POL_RVO;
+            const uint32_t st0 = W.tst[tid];
+            const bool is_rvo = C.valid && C.active && !(st0 & CAGYM_FLAG_DONE) && ST_POLICY(st0) == CAGYM_POL_RVO;
             bool need3 = false;
             if (is_rvo) {
+                const Agent A = lds_load_agent(W, tid);
                 const OrcaEgo E = orca_ego(A, D.dt);
                 const int nn = (C.n - 1) < CAGYM_MAXNB ? (C.n - 1) : CAGYM_MAXNB;
                 float nvx, nvy;
-                const int fail = orca_lp2(W.sorted, tid, nn, E.max_speed, E.pvx, E.pvy, false, nvx, nvy);
+                const int fail = orca_lp2_unrolled(W.sorted, tid, nn, E.max_speed, E.pvx, E.pvy, nvx, nvy);
                 W.lpv[tid] = make_float2(nvx, nvy);
                 W.lpk[tid] = fail;
                 W.lpr[tid] = E.max_speed;
@@ -213,9 +248,10 @@ __device__ inline void step_core2(const CagymDev& D, const Lds2& W, LaneCtx& C, 
         }
         STAMP(9);
     }
-    if (agent_lane) {
+    if (agent_lane && C.valid && C.active) {
+        Agent A = lds_load_agent(W, tid);
         float a0 = 0.f, a1 = 0.f;
-        if (C.valid && C.active && !(A.st & CAGYM_FLAG_DONE)) {
+        if (!(A.st & CAGYM_FLAG_DONE)) {
             double d0 = 0.0, d1 = 0.0;
             switch (ST_POLICY(A.st)) {
                 case CAGYM_POL_STATIC: break;
@@ -237,8 +273,8 @@ __device__ inline void step_core2(const CagymDev& D, const Lds2& W, LaneCtx& C, 
             a0 = (float)d0;
             a1 = (float)d1;
         }
-        if (C.valid && C.active) take_action(A, a0, a1, D.dt);
-        publish_tile2(W, A, tid);  // nobody reads the tile here (P1 / LP3 readers are behind their barriers)
+        take_action(A, a0, a1, D.dt);
+        lds_store_moved(W, A, tid);  // nobody reads the tile here (P1 / LP3 readers are behind their barriers)
     }
     __syncthreads();  // post-move tile visible; LP scratch (union, pre-move view) is dead
     STAMP(3);
@@ -276,7 +312,10 @@ __device__ inline void step_core2(const CagymDev& D, const Lds2& W, LaneCtx& C, 
     // ---- S2: _compute_rewards (env.py:502-567), _check_which_agents_done (:711-738), auto-reset -----------
     if (agent_lane) {
         float reward = 0.f;
+        Agent A;
+        A.st = W.tst[tid];
         if (C.valid && C.active) {
+            A.px = W.tpx[tid]; A.py = W.tpy[tid]; A.r = W.tr[tid];
             bool coll_wall = false;
             double dmin = INFINITY;
             uint32_t hits = 0;
@@ -345,15 +384,13 @@ __device__ inline void step_core2(const CagymDev& D, const Lds2& W, LaneCtx& C, 
                     C.n = D.sc_nagents[sidx];
                     C.active = C.slot < C.n;
                     init_agent(D, A, sidx, C.slot, C.active);
+                    lds_store_agent(W, A, tid);
+                    if (C.slot == 0) W.wn[C.wl] = C.n;
                 }
-                publish_tile2(W, A, tid);
-                if (C.valid && C.slot == 0) W.wn[C.wl] = C.n;
             }
         }
+        W.tst[tid] = A.st;
         if (tid == 0) W.flag[0] = any_reset ? 1 : 0;
-        // reference axes of every agent for the OAS projection (agent.py:250-269)
-        W.tprx[tid] = (C.valid && C.active) ? A.prx : 0.0;
-        W.tpry[tid] = (C.valid && C.active) ? A.pry : 0.0;
     }
     __syncthreads();
     STAMP(5);
@@ -428,6 +465,7 @@ __device__ inline void step_core2(const CagymDev& D, const Lds2& W, LaneCtx& C, 
         if (out.obs_ego) {
             float4* e = reinterpret_cast<float4*>(out.obs_ego + aidx * CAGYM_EGO_WIDTH);
             if (C.active) {
+                const Agent A = lds_load_agent(W, tid);
                 e[0] = make_float4((float)A.dg, (float)(A.gx - A.px), (float)(A.gy - A.py), (float)A.r);
                 e[1] = make_float4((float)A.he, (float)A.h, (float)A.px, (float)A.py);
                 e[2] = make_float4((float)A.pref, (float)nobs, ST_POLICY(A.st) == CAGYM_POL_LEARNING ? 1.f : 0.f, 0.f);
@@ -445,17 +483,22 @@ __global__ void __launch_bounds__(NT, (NT <= 256 ? 3 : 2)) k_rollout2(CagymDev D
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     Lds2 W = carve_lds2(smem, D.M);
     LaneCtx C = make_ctx(D);
-    Agent A = {};
     const bool agent_lane = threadIdx.x < CAGYM_WAVE;
     const size_t aidx = (size_t)C.world * D.M + C.slot;
     float ep_ret = 0.f;
     int ep_len = 0;
     if (!agent_lane) C.valid = C.active = false;
-    if (C.valid) {
-        load_agent(D, A, aidx);
-        if (C.slot == 0) { ep_ret = D.ep_return[C.world]; ep_len = D.ep_len[C.world]; }
+    if (agent_lane) {
+        Agent A = {};
+        if (C.valid) {
+            load_agent(D, A, aidx);
+            if (C.slot == 0) { ep_ret = D.ep_return[C.world]; ep_len = D.ep_len[C.world]; }
+        }
+        lds_store_agent(W, A, threadIdx.x);
+        if (C.wl < C.wpw && C.slot == 0) W.wn[C.wl] = C.valid ? C.n : 0;
     }
     const size_t NM = (size_t)D.N * D.M;
+#pragma nounroll
     for (int t = 0; t < n_steps; t++) {
         CagymOut o;
         o.obs_oas = out.obs_oas ? out.obs_oas + (size_t)t * NM * (D.M - 1) * 10 : nullptr;
@@ -464,9 +507,10 @@ __global__ void __launch_bounds__(NT, (NT <= 256 ? 3 : 2)) k_rollout2(CagymDev D
         o.reward = out.reward ? out.reward + (size_t)t * NM : nullptr;
         o.flags = out.flags ? out.flags + (size_t)t * NM : nullptr;
         o.game_over = out.game_over ? out.game_over + (size_t)t * D.N : nullptr;
-        step_core2<NT, AUTO_RESET>(D, W, C, A, nullptr, o, ep_ret, ep_len, any_rvo != 0);
+        step_core2<NT, AUTO_RESET>(D, W, C, nullptr, o, ep_ret, ep_len, any_rvo != 0);
     }
     if (C.valid) {
+        const Agent A = lds_load_agent(W, threadIdx.x);  // own lane's record: no barrier needed
         store_agent(D, A, aidx, true);
         if (C.slot == 0) {
             D.ep_return[C.world] = ep_ret;
@@ -482,18 +526,23 @@ __global__ void __launch_bounds__(NT) k_step2(CagymDev D, const float* ext, Cagy
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     Lds2 W = carve_lds2(smem, D.M);
     LaneCtx C = make_ctx(D);
-    Agent A = {};
     const bool agent_lane = threadIdx.x < CAGYM_WAVE;
     const size_t aidx = (size_t)C.world * D.M + C.slot;
     float ep_ret = 0.f;
     int ep_len = 0;
     if (!agent_lane) C.valid = C.active = false;
-    if (C.valid) {
-        load_agent(D, A, aidx);
-        if (C.slot == 0) { ep_ret = D.ep_return[C.world]; ep_len = D.ep_len[C.world]; }
+    if (agent_lane) {
+        Agent A = {};
+        if (C.valid) {
+            load_agent(D, A, aidx);
+            if (C.slot == 0) { ep_ret = D.ep_return[C.world]; ep_len = D.ep_len[C.world]; }
+        }
+        lds_store_agent(W, A, threadIdx.x);
+        if (C.wl < C.wpw && C.slot == 0) W.wn[C.wl] = C.valid ? C.n : 0;
     }
-    step_core2<NT, false>(D, W, C, A, ext, out, ep_ret, ep_len, any_rvo != 0);
+    step_core2<NT, false>(D, W, C, ext, out, ep_ret, ep_len, any_rvo != 0);
     if (C.valid) {
+        const Agent A = lds_load_agent(W, threadIdx.x);
         store_agent(D, A, aidx, false);
         if (C.slot == 0) { D.ep_return[C.world] = ep_ret; D.ep_len[C.world] = ep_len; }
     }

@@ -251,6 +251,68 @@ __device__ inline void orca_action(const NbrTile& T, float4* L, float4* P, int l
     orca_solve(L, P, lane, nn, E, A, dt, out_speed, out_dh);
 }
 
+// linearProgram2 (directionOpt = false) with the half-planes in registers and both loops fully unrolled.
+// linearProgram1's clipping is written without early exits: tLeft only grows and tRight only shrinks, so
+// "tLeft > tRight at some point" == "tLeft > tRight at the end", and the "parallel and outside" test is an OR;
+// the i independent (den, num, t) triples of line i then overlap instead of forming a chain of dependent LDS
+// reads and divisions.  Results are identical to orca_lp2/orca_lp1 (checked bitwise against generation 1).
+__device__ inline int orca_lp2_unrolled(const float4* L, int lane, int n, float radius, float ox, float oy, float& rx,
+                                        float& ry) {
+    float4 ln[CAGYM_MAXNB];
+#pragma unroll
+    for (int i = 0; i < CAGYM_MAXNB; i++) ln[i] = L[i * CAGYM_WAVE + lane];  // slots >= n: stale but in bounds, unused
+    if (ox * ox + oy * oy > radius * radius) {
+        float inv = 1.0f / sqrtf(ox * ox + oy * oy);
+        rx = ox * inv * radius;
+        ry = oy * inv * radius;
+    } else {
+        rx = ox;
+        ry = oy;
+    }
+    int fail = n;
+    bool done = false;
+#pragma unroll
+    for (int i = 0; i < CAGYM_MAXNB; i++) {
+        if (done || i >= n) continue;
+        if (!(detf(ln[i].z, ln[i].w, ln[i].x - rx, ln[i].y - ry) > 0.0f)) continue;
+        // linearProgram1(i)
+        const float dot = ln[i].x * ln[i].z + ln[i].y * ln[i].w;
+        const float disc = dot * dot + radius * radius - (ln[i].x * ln[i].x + ln[i].y * ln[i].y);
+        bool ok = !(disc < 0.0f);
+        float tl = 0.f, tr = 0.f;
+        if (ok) {
+            const float sq = sqrtf(disc);
+            tl = -dot - sq;
+            tr = -dot + sq;
+            bool bad = false;
+#pragma unroll
+            for (int j = 0; j < i; j++) {
+                const float den = detf(ln[i].z, ln[i].w, ln[j].z, ln[j].w);
+                const float num = detf(ln[j].z, ln[j].w, ln[i].x - ln[j].x, ln[i].y - ln[j].y);
+                const bool par = fabsf(den) <= RVO_EPS;
+                const float t = num / den;
+                bad |= par && (num < 0.0f);
+                if (!par) {
+                    if (den >= 0.0f) tr = tr < t ? tr : t;
+                    else tl = tl > t ? tl : t;
+                }
+            }
+            ok = !bad && !(tl > tr);
+        }
+        if (ok) {
+            float t = ln[i].z * (ox - ln[i].x) + ln[i].w * (oy - ln[i].y);
+            if (t < tl) t = tl;
+            else if (t > tr) t = tr;
+            rx = ln[i].x + t * ln[i].z;
+            ry = ln[i].y + t * ln[i].w;
+        } else {
+            fail = i;  // result keeps the value it had before this line (tempResult)
+            done = true;
+        }
+    }
+    return fail;
+}
+
 // ---- cooperative linearProgram3 --------------------------------------------------------------------
 // One ego per 16-lane group, lane j <-> half-plane j.  Same arithmetic as orca_lp3/orca_lp2/orca_lp1 above:
 // the interval clipping of linearProgram1 (tLeft = max, tRight = min, "parallel and outside" / tLeft > tRight
