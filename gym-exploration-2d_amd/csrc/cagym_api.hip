@@ -144,15 +144,18 @@ int cagym_create(const cagym_config* cfg, void** env_out) {
         if (g && (!strcmp(g, "v1") || !strcmp(g, "1"))) e->generation = 1;
         int lds2 = (int)cagym_lds2_bytes((int)M);
         if (lds2 > 160 * 1024) e->generation = 1;
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<256>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<512>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<512>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<256, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<512, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<512, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<256, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<512, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<512, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<256, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<256, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<256, 10, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<256, 10, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<512, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<512, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<256, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<512, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<512, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<256, 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<512, 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<512, 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
     }
     (void)hipGetLastError();
     *env_out = e;
@@ -247,9 +250,10 @@ int cagym_step(void* env, const float* ext_actions, const cagym_outputs* out, vo
     const int M = e->cfg.max_agents;
     if (e->generation == 2) {
         const size_t lds2 = cagym_lds2_bytes(M);
-        if (M <= 12) hipLaunchKernelGGL((k_step2<256>), dim3(n_waves(e)), dim3(256), lds2, st, e->D, ext_actions, o, e->any_rvo);
-        else if (M <= 16) hipLaunchKernelGGL((k_step2<512>), dim3(n_waves(e)), dim3(512), lds2, st, e->D, ext_actions, o, e->any_rvo);
-        else hipLaunchKernelGGL((k_step2<512>), dim3(n_waves(e)), dim3(512), lds2, st, e->D, ext_actions, o, e->any_rvo);
+        if (M == 10) hipLaunchKernelGGL((k_step2<256, 10>), dim3(n_waves(e)), dim3(256), lds2, st, e->D, ext_actions, o, e->any_rvo);
+        else if (M <= 12) hipLaunchKernelGGL((k_step2<256, 0>), dim3(n_waves(e)), dim3(256), lds2, st, e->D, ext_actions, o, e->any_rvo);
+        else if (M <= 16) hipLaunchKernelGGL((k_step2<512, 0>), dim3(n_waves(e)), dim3(512), lds2, st, e->D, ext_actions, o, e->any_rvo);
+        else hipLaunchKernelGGL((k_step2<512, 0>), dim3(n_waves(e)), dim3(512), lds2, st, e->D, ext_actions, o, e->any_rvo);
     } else
     hipLaunchKernelGGL(k_step, dim3(n_waves(e)), dim3(64), cagym_lds_bytes(e->cfg.max_agents), st, e->D, ext_actions, o);
     HIPCHK(e, hipGetLastError());
@@ -271,13 +275,14 @@ int cagym_rollout(void* env, int n_steps, int auto_reset, const cagym_outputs* o
     if (e->generation == 2) {
         const size_t lds2 = cagym_lds2_bytes(M);
         const dim3 g(n_waves(e));
-#define ROLL2(NT)                                                                                                  \
+#define ROLL2(NT, MT)                                                                                              \
     do {                                                                                                           \
-        if (auto_reset) hipLaunchKernelGGL((k_rollout2<NT, true>), g, dim3(NT), lds2, st, e->D, n_steps, o, e->any_rvo); \
-        else hipLaunchKernelGGL((k_rollout2<NT, false>), g, dim3(NT), lds2, st, e->D, n_steps, o, e->any_rvo);         \
+        if (auto_reset) hipLaunchKernelGGL((k_rollout2<NT, MT, true>), g, dim3(NT), lds2, st, e->D, n_steps, o, e->any_rvo); \
+        else hipLaunchKernelGGL((k_rollout2<NT, MT, false>), g, dim3(NT), lds2, st, e->D, n_steps, o, e->any_rvo);         \
     } while (0)
-        if (M <= 12) ROLL2(256);
-        else ROLL2(512);
+        if (M == 10) ROLL2(256, 10);
+        else if (M <= 12) ROLL2(256, 0);
+        else ROLL2(512, 0);
 #undef ROLL2
     } else if (auto_reset)
         hipLaunchKernelGGL(k_rollout<true>, dim3(n_waves(e)), dim3(64), lds, st, e->D, n_steps, o);

@@ -131,6 +131,23 @@ __device__ __forceinline__ Agent lds_load_agent(const Lds2& W, int lane) {
     return A;
 }
 
+__device__ __forceinline__ LaneCtx make_ctx2(const CagymDev& D, int M) {
+    LaneCtx C;
+    C.lane = threadIdx.x;
+    C.wpw = CAGYM_WAVE / M;
+    C.wl = C.lane / M;
+    C.slot = C.lane - C.wl * M;
+    C.base = C.wl * M;
+    C.world = blockIdx.x * C.wpw + C.wl;
+    int rem = D.N - (int)blockIdx.x * C.wpw;
+    C.worlds_valid = rem < C.wpw ? rem : C.wpw;
+    C.valid = C.wl < C.wpw && C.world < D.N;
+    C.n = C.valid ? D.n_agents[C.world] : 0;
+    C.episode = C.valid ? D.episode[C.world] : 0;
+    C.active = C.valid && C.slot < C.n;
+    return C;
+}
+
 // pair slot p = agent * M + j  ->  (agent lane a, neighbour slot j, world_local wl, agent slot sl)
 struct PairIdx {
     int a, j, wl, sl;
@@ -146,14 +163,14 @@ __device__ __forceinline__ PairIdx pair_of(int p, int M, uint32_t inv_m) {
 
 // One env.step() of the workgroup's worlds.  Agent registers A live on wave 0 (tid < 64) only; the pair
 // phases keep nothing in registers across barriers (everything is re-read from LDS).
-template <int NT, bool AUTO_RESET>
+template <int NT, int MT, bool AUTO_RESET>
 __device__ inline void step_core2(const CagymDev& D, const Lds2& W, LaneCtx& C, const float* ext, const CagymOut& out,
                                   float& ep_ret, int& ep_len, bool any_rvo) {
     int tid = threadIdx.x;
     // opaque per step: keeps the compiler from hoisting every (agent, neighbour) index derived from tid out of
     // the rollout's step loop (that hoisting cost ~100 VGPRs and spilled; recomputing is a few ALU ops)
     asm volatile("" : "+v"(tid));
-    const int M = D.M, K = M - 1, MP = cagym_mp(M);
+    const int M = MT ? MT : D.M, K = M - 1, MP = cagym_mp(M);  // MT > 0: M is a compile-time constant
     const uint32_t inv_m = (uint32_t)(0x100000000ull / (uint32_t)M) + 1u;
     const bool agent_lane = tid < CAGYM_WAVE;
     const size_t aidx = (size_t)C.world * M + C.slot;
@@ -478,13 +495,14 @@ __device__ inline void step_core2(const CagymDev& D, const Lds2& W, LaneCtx& C, 
     // the next S0 barrier orders these staging reads before the union is rewritten
 }
 
-template <int NT, bool AUTO_RESET>
+template <int NT, int MT, bool AUTO_RESET>
 __global__ void __launch_bounds__(NT, (NT <= 256 ? 3 : 2)) k_rollout2(CagymDev D, int n_steps, CagymOut out, int any_rvo) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    Lds2 W = carve_lds2(smem, D.M);
-    LaneCtx C = make_ctx(D);
+    const int M = MT ? MT : D.M;
+    Lds2 W = carve_lds2(smem, M);
+    LaneCtx C = make_ctx2(D, M);
     const bool agent_lane = threadIdx.x < CAGYM_WAVE;
-    const size_t aidx = (size_t)C.world * D.M + C.slot;
+    const size_t aidx = (size_t)C.world * M + C.slot;
     float ep_ret = 0.f;
     int ep_len = 0;
     if (!agent_lane) C.valid = C.active = false;
@@ -497,17 +515,17 @@ __global__ void __launch_bounds__(NT, (NT <= 256 ? 3 : 2)) k_rollout2(CagymDev D
         lds_store_agent(W, A, threadIdx.x);
         if (C.wl < C.wpw && C.slot == 0) W.wn[C.wl] = C.valid ? C.n : 0;
     }
-    const size_t NM = (size_t)D.N * D.M;
+    const size_t NM = (size_t)D.N * M;
 #pragma nounroll
     for (int t = 0; t < n_steps; t++) {
         CagymOut o;
-        o.obs_oas = out.obs_oas ? out.obs_oas + (size_t)t * NM * (D.M - 1) * 10 : nullptr;
+        o.obs_oas = out.obs_oas ? out.obs_oas + (size_t)t * NM * (M - 1) * 10 : nullptr;
         o.obs_ego = out.obs_ego ? out.obs_ego + (size_t)t * NM * CAGYM_EGO_WIDTH : nullptr;
         o.laserscan = nullptr;
         o.reward = out.reward ? out.reward + (size_t)t * NM : nullptr;
         o.flags = out.flags ? out.flags + (size_t)t * NM : nullptr;
         o.game_over = out.game_over ? out.game_over + (size_t)t * D.N : nullptr;
-        step_core2<NT, AUTO_RESET>(D, W, C, nullptr, o, ep_ret, ep_len, any_rvo != 0);
+        step_core2<NT, MT, AUTO_RESET>(D, W, C, nullptr, o, ep_ret, ep_len, any_rvo != 0);
     }
     if (C.valid) {
         const Agent A = lds_load_agent(W, threadIdx.x);  // own lane's record: no barrier needed
@@ -521,13 +539,14 @@ __global__ void __launch_bounds__(NT, (NT <= 256 ? 3 : 2)) k_rollout2(CagymDev D
     }
 }
 
-template <int NT>
+template <int NT, int MT>
 __global__ void __launch_bounds__(NT) k_step2(CagymDev D, const float* ext, CagymOut out, int any_rvo) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    Lds2 W = carve_lds2(smem, D.M);
-    LaneCtx C = make_ctx(D);
+    const int M = MT ? MT : D.M;
+    Lds2 W = carve_lds2(smem, M);
+    LaneCtx C = make_ctx2(D, M);
     const bool agent_lane = threadIdx.x < CAGYM_WAVE;
-    const size_t aidx = (size_t)C.world * D.M + C.slot;
+    const size_t aidx = (size_t)C.world * M + C.slot;
     float ep_ret = 0.f;
     int ep_len = 0;
     if (!agent_lane) C.valid = C.active = false;
@@ -540,7 +559,7 @@ __global__ void __launch_bounds__(NT) k_step2(CagymDev D, const float* ext, Cagy
         lds_store_agent(W, A, threadIdx.x);
         if (C.wl < C.wpw && C.slot == 0) W.wn[C.wl] = C.valid ? C.n : 0;
     }
-    step_core2<NT, false>(D, W, C, ext, out, ep_ret, ep_len, any_rvo != 0);
+    step_core2<NT, MT, false>(D, W, C, ext, out, ep_ret, ep_len, any_rvo != 0);
     if (C.valid) {
         const Agent A = lds_load_agent(W, threadIdx.x);
         store_agent(D, A, aidx, false);
