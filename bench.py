@@ -66,6 +66,7 @@ def main():
     ap.add_argument("--roll", type=int, default=64, help="env steps per launch")
     ap.add_argument("--per-step-launch", action="store_true", help="one cagym_step launch per env step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pool-factor", type=int, default=8, help="scenario pool size = factor x worlds")
     args = ap.parse_args()
 
     import torch
@@ -86,7 +87,7 @@ def main():
     BEnv = importlib.import_module("gym-exploration-2d_amd.batched_env").BatchedCollisionAvoidanceEnv
     N, M = args.worlds, args.agents
     pol = scen.POLICY_RVO if args.policy == "rvo" else scen.POLICY_NONCOOP
-    S = 8 * N
+    S = args.pool_factor * N
     a6 = scen.random_worlds_fast(S, M, seed=1234 + 7919 * rank)
     env = BEnv(N, M, n_scenarios=S, game_over_mode="all", device=device)
     env.set_scenarios(a6, pol, scen.DYN_UNICYCLE, coop=np.full((S, M), 0.5))
@@ -164,7 +165,7 @@ def main():
             "agent_steps_per_s": value * M,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_step+k_reset" if args.per_step_launch else "k_rollout<true>",
+                         "kernel": "k_step2+k_reset" if args.per_step_launch else "k_rollout2<256, 10, true>",
                          "launch_ms": launch_ms, "alg_bytes_per_agent_step": balg},
             "episodes": st,
         }

@@ -14,7 +14,10 @@ SOURCES = ["cagym_api.hip"]
 HEADERS = ["cagym_device.h", "cagym_orca.h", "cagym_kernels.h", "cagym_kernels2.h", "cagym_ig.h", "../../include/cagym.h"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
-         "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wno-unused-value"]
+         "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wno-unused-value",
+         # MachineLICM hoists ~70 fp64 polynomial literals (sincos/atan2) out of the rollout's step loop and
+         # keeps them in VGPRs: 168 VGPRs + spills instead of 106 (measured)
+         "-mllvm", "-disable-machine-licm"]
 
 
 def _torch_lib_dir():
