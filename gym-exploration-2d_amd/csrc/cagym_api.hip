@@ -70,6 +70,20 @@ CagymOut to_out(const cagym_outputs* o) {
     return r;
 }
 
+#ifndef WPW10
+#define WPW10 5 /* worlds per workgroup of the M = 10 specialisation: 500 pair slots = 2 rounds of 256 lanes */
+#endif
+
+inline int n_wg2(const Env* e) {
+    const int M = e->cfg.max_agents;
+    const int wpw = M == 10 ? WPW10 : CAGYM_WAVE / M;
+    return (e->cfg.n_worlds + wpw - 1) / wpw;
+}
+inline size_t lds2_bytes(const Env* e) {
+    const int M = e->cfg.max_agents;
+    return cagym_lds2_bytes(M, cagym_as(M, M == 10 ? WPW10 : 0));
+}
+
 inline int n_waves(const Env* e) {
     int wpw = CAGYM_WAVE / e->cfg.max_agents;
     return (e->cfg.n_worlds + wpw - 1) / wpw;
@@ -142,20 +156,20 @@ int cagym_create(const cagym_config* cfg, void** env_out) {
     {
         const char* g = getenv("CAGYM_KERNEL");
         if (g && (!strcmp(g, "v1") || !strcmp(g, "1"))) e->generation = 1;
-        int lds2 = (int)cagym_lds2_bytes((int)M);
+        int lds2 = (int)lds2_bytes(e);
         if (lds2 > 160 * 1024) e->generation = 1;
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<256, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<256, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<256, 10, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<256, 10, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<512, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<512, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<256, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<512, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<512, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<256, 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<512, 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<512, 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<256, 0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<256, 10, WPW10>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<256, 10, WPW10, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<256, 10, WPW10, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<512, 0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<512, 0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<256, 0, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<512, 0, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<512, 0, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<256, 0, 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<512, 0, 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<512, 0, 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
     }
     (void)hipGetLastError();
     *env_out = e;
@@ -249,11 +263,11 @@ int cagym_step(void* env, const float* ext_actions, const cagym_outputs* out, vo
     CagymOut o = to_out(out);
     const int M = e->cfg.max_agents;
     if (e->generation == 2) {
-        const size_t lds2 = cagym_lds2_bytes(M);
-        if (M == 10) hipLaunchKernelGGL((k_step2<256, 10>), dim3(n_waves(e)), dim3(256), lds2, st, e->D, ext_actions, o, e->any_rvo);
-        else if (M <= 12) hipLaunchKernelGGL((k_step2<256, 0>), dim3(n_waves(e)), dim3(256), lds2, st, e->D, ext_actions, o, e->any_rvo);
-        else if (M <= 16) hipLaunchKernelGGL((k_step2<512, 0>), dim3(n_waves(e)), dim3(512), lds2, st, e->D, ext_actions, o, e->any_rvo);
-        else hipLaunchKernelGGL((k_step2<512, 0>), dim3(n_waves(e)), dim3(512), lds2, st, e->D, ext_actions, o, e->any_rvo);
+        const size_t lds2 = lds2_bytes(e);
+        if (M == 10) hipLaunchKernelGGL((k_step2<256, 10, WPW10>), dim3(n_wg2(e)), dim3(256), lds2, st, e->D, ext_actions, o, e->any_rvo);
+        else if (M <= 12) hipLaunchKernelGGL((k_step2<256, 0, 0>), dim3(n_waves(e)), dim3(256), lds2, st, e->D, ext_actions, o, e->any_rvo);
+        else if (M <= 16) hipLaunchKernelGGL((k_step2<512, 0, 0>), dim3(n_waves(e)), dim3(512), lds2, st, e->D, ext_actions, o, e->any_rvo);
+        else hipLaunchKernelGGL((k_step2<512, 0, 0>), dim3(n_waves(e)), dim3(512), lds2, st, e->D, ext_actions, o, e->any_rvo);
     } else
     hipLaunchKernelGGL(k_step, dim3(n_waves(e)), dim3(64), cagym_lds_bytes(e->cfg.max_agents), st, e->D, ext_actions, o);
     HIPCHK(e, hipGetLastError());
@@ -273,16 +287,16 @@ int cagym_rollout(void* env, int n_steps, int auto_reset, const cagym_outputs* o
     size_t lds = cagym_lds_bytes(e->cfg.max_agents);
     const int M = e->cfg.max_agents;
     if (e->generation == 2) {
-        const size_t lds2 = cagym_lds2_bytes(M);
-        const dim3 g(n_waves(e));
-#define ROLL2(NT, MT)                                                                                              \
+        const size_t lds2 = lds2_bytes(e);
+        const dim3 g(n_wg2(e));
+#define ROLL2(NT, MT, WP)                                                                                              \
     do {                                                                                                           \
-        if (auto_reset) hipLaunchKernelGGL((k_rollout2<NT, MT, true>), g, dim3(NT), lds2, st, e->D, n_steps, o, e->any_rvo); \
-        else hipLaunchKernelGGL((k_rollout2<NT, MT, false>), g, dim3(NT), lds2, st, e->D, n_steps, o, e->any_rvo);         \
+        if (auto_reset) hipLaunchKernelGGL((k_rollout2<NT, MT, WP, true>), g, dim3(NT), lds2, st, e->D, n_steps, o, e->any_rvo); \
+        else hipLaunchKernelGGL((k_rollout2<NT, MT, WP, false>), g, dim3(NT), lds2, st, e->D, n_steps, o, e->any_rvo);         \
     } while (0)
-        if (M == 10) ROLL2(256, 10);
-        else if (M <= 12) ROLL2(256, 0);
-        else ROLL2(512, 0);
+        if (M == 10) ROLL2(256, 10, WPW10);
+        else if (M <= 12) ROLL2(256, 0, 0);
+        else ROLL2(512, 0, 0);
 #undef ROLL2
     } else if (auto_reset)
         hipLaunchKernelGGL(k_rollout<true>, dim3(n_waves(e)), dim3(64), lds, st, e->D, n_steps, o);

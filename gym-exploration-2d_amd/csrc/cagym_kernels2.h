@@ -62,42 +62,45 @@ struct Lds2 {
 __host__ __device__ inline size_t a16(size_t x) { return (x + 15) & ~(size_t)15; }
 __host__ __device__ inline int cagym_mp(int M) { return (M + 3) & ~3; }
 
-__host__ __device__ inline size_t cagym_lds2_bytes(int M) {
+// AS = agent slots per workgroup (worlds per workgroup x M, rounded up to 4); 64 when a full wave is used
+__host__ __device__ inline int cagym_as(int M, int wpw) { return wpw > 0 ? ((wpw * M + 3) & ~3) : 64; }
+
+__host__ __device__ inline size_t cagym_lds2_bytes(int M, int AS = 64) {
     const size_t MP = cagym_mp(M);
-    size_t head = 20 * 64 * 8 + 64 * 8 + 64 * 4 + 64 * 4 + 64 * 4 + 32 * 4 + 16 + 64 * 8 + 64 * 4 + 64 * 4 + 16;
-    size_t pre = 64 * MP * 4 + 64 * MP * 16 + 2 * (size_t)CAGYM_MAXNB * 64 * 16;
-    size_t post = 2 * 64 * MP * 8 + 64 * MP + (size_t)64 * (M - 1) * 40;
+    size_t head = 20 * AS * 8 + AS * 8 + AS * 4 + AS * 4 + AS * 4 + 32 * 4 + 16 + AS * 8 + AS * 4 + AS * 4 + 16;
+    size_t pre = AS * MP * 4 + AS * MP * 16 + 2 * (size_t)CAGYM_MAXNB * AS * 16;
+    size_t post = 2 * AS * MP * 8 + AS * MP + (size_t)AS * (M - 1) * 40;
     return a16(head) + (pre > post ? pre : post);
 }
 
-__device__ __forceinline__ Lds2 carve_lds2(unsigned char* smem, int M) {
+__device__ __forceinline__ Lds2 carve_lds2(unsigned char* smem, int M, int AS = 64) {
     Lds2 W;
     const size_t MP = cagym_mp(M);
     W.tpx = reinterpret_cast<double*>(smem);
-    W.tpy = W.tpx + 64; W.tvx = W.tpy + 64; W.tvy = W.tvx + 64; W.tr = W.tvy + 64; W.tprx = W.tr + 64; W.tpry = W.tprx + 64;
-    W.th = W.tpry + 64; W.the = W.th + 64; W.tdg = W.the + 64; W.ttrem = W.tdg + 64; W.tt = W.ttrem + 64;
-    W.tgx = W.tt + 64; W.tgy = W.tgx + 64; W.tpref = W.tgy + 64; W.tspeed = W.tpref + 64; W.tdh = W.tspeed + 64;
-    W.taux0 = W.tdh + 64; W.taux1 = W.taux0 + 64; W.tcoopd = W.taux1 + 64;
-    W.tact = reinterpret_cast<float2*>(W.tcoopd + 64);
-    W.tcoop = reinterpret_cast<float*>(W.tact + 64);
-    W.tst = reinterpret_cast<uint32_t*>(W.tcoop + 64);
-    W.tstep = reinterpret_cast<int*>(W.tst + 64);
-    W.wn = W.tstep + 64;
+    W.tpy = W.tpx + AS; W.tvx = W.tpy + AS; W.tvy = W.tvx + AS; W.tr = W.tvy + AS; W.tprx = W.tr + AS; W.tpry = W.tprx + AS;
+    W.th = W.tpry + AS; W.the = W.th + AS; W.tdg = W.the + AS; W.ttrem = W.tdg + AS; W.tt = W.ttrem + AS;
+    W.tgx = W.tt + AS; W.tgy = W.tgx + AS; W.tpref = W.tgy + AS; W.tspeed = W.tpref + AS; W.tdh = W.tspeed + AS;
+    W.taux0 = W.tdh + AS; W.taux1 = W.taux0 + AS; W.tcoopd = W.taux1 + AS;
+    W.tact = reinterpret_cast<float2*>(W.tcoopd + AS);
+    W.tcoop = reinterpret_cast<float*>(W.tact + AS);
+    W.tst = reinterpret_cast<uint32_t*>(W.tcoop + AS);
+    W.tstep = reinterpret_cast<int*>(W.tst + AS);
+    W.wn = W.tstep + AS;
     W.flag = W.wn + 32;
     W.lpv = reinterpret_cast<float2*>(W.flag + 4);
-    W.lpk = reinterpret_cast<int*>(W.lpv + 64);
-    W.lpr = reinterpret_cast<float*>(W.lpk + 64);
-    W.lpmask = reinterpret_cast<unsigned long long*>(W.lpr + 64);
-    size_t head = 20 * 64 * 8 + 64 * 8 + 64 * 4 + 64 * 4 + 64 * 4 + 32 * 4 + 16 + 64 * 8 + 64 * 4 + 64 * 4 + 16;
+    W.lpk = reinterpret_cast<int*>(W.lpv + AS);
+    W.lpr = reinterpret_cast<float*>(W.lpk + AS);
+    W.lpmask = reinterpret_cast<unsigned long long*>(W.lpr + AS);
+    size_t head = 20 * AS * 8 + AS * 8 + AS * 4 + AS * 4 + AS * 4 + 32 * 4 + 16 + AS * 8 + AS * 4 + AS * 4 + 16;
     unsigned char* u = smem + a16(head);
     W.dsq = reinterpret_cast<float*>(u);
-    W.lines = reinterpret_cast<float4*>(u + 64 * MP * 4);
-    W.sorted = W.lines + 64 * MP;
-    W.proj = W.sorted + CAGYM_MAXNB * 64;
+    W.lines = reinterpret_cast<float4*>(u + AS * MP * 4);
+    W.sorted = W.lines + AS * MP;
+    W.proj = W.sorted + CAGYM_MAXNB * AS;
     W.keys = reinterpret_cast<double*>(u);
-    W.gap = W.keys + 64 * MP;
-    W.hit = reinterpret_cast<uint8_t*>(W.gap + 64 * MP);
-    W.oas = reinterpret_cast<float*>(W.hit + 64 * MP);
+    W.gap = W.keys + AS * MP;
+    W.hit = reinterpret_cast<uint8_t*>(W.gap + AS * MP);
+    W.oas = reinterpret_cast<float*>(W.hit + AS * MP);
     return W;
 }
 
@@ -131,10 +134,10 @@ __device__ __forceinline__ Agent lds_load_agent(const Lds2& W, int lane) {
     return A;
 }
 
-__device__ __forceinline__ LaneCtx make_ctx2(const CagymDev& D, int M) {
+__device__ __forceinline__ LaneCtx make_ctx2(const CagymDev& D, int M, int wpw) {
     LaneCtx C;
     C.lane = threadIdx.x;
-    C.wpw = CAGYM_WAVE / M;
+    C.wpw = wpw;
     C.wl = C.lane / M;
     C.slot = C.lane - C.wl * M;
     C.base = C.wl * M;
@@ -163,7 +166,7 @@ __device__ __forceinline__ PairIdx pair_of(int p, int M, uint32_t inv_m) {
 
 // One env.step() of the workgroup's worlds.  Agent registers A live on wave 0 (tid < 64) only; the pair
 // phases keep nothing in registers across barriers (everything is re-read from LDS).
-template <int NT, int MT, bool AUTO_RESET>
+template <int NT, int MT, int WPWT, bool AUTO_RESET>
 __device__ inline void step_core2(const CagymDev& D, const Lds2& W, LaneCtx& C, const float* ext, const CagymOut& out,
                                   float& ep_ret, int& ep_len, bool any_rvo) {
     int tid = threadIdx.x;
@@ -171,8 +174,9 @@ __device__ inline void step_core2(const CagymDev& D, const Lds2& W, LaneCtx& C, 
     // the rollout's step loop (that hoisting cost ~100 VGPRs and spilled; recomputing is a few ALU ops)
     asm volatile("" : "+v"(tid));
     const int M = MT ? MT : D.M, K = M - 1, MP = cagym_mp(M);  // MT > 0: M is a compile-time constant
+    const int AS = cagym_as(M, WPWT);                           // LDS agent stride (64, or worlds-per-WG x M)
     const uint32_t inv_m = (uint32_t)(0x100000000ull / (uint32_t)M) + 1u;
-    const bool agent_lane = tid < CAGYM_WAVE;
+    const bool agent_lane = tid < C.wpw * M;  // wave 0, one lane per agent slot of this workgroup
     const size_t aidx = (size_t)C.world * M + C.slot;
     const int npairs = C.wpw * M * M;
     STAMP_BEGIN();
@@ -216,7 +220,7 @@ __device__ inline void step_core2(const CagymDev& D, const Lds2& W, LaneCtx& C, 
                 rank += (v.z < dq) || (v.z == dq && l4 + 2 < q.j);
                 rank += (v.w < dq) || (v.w == dq && l4 + 3 < q.j);
             }
-            if (rank < CAGYM_MAXNB) W.sorted[rank * CAGYM_WAVE + q.a] = W.lines[q.a * MP + q.j];
+            if (rank < CAGYM_MAXNB) W.sorted[rank * AS + q.a] = W.lines[q.a * MP + q.j];
         }
         __syncthreads();
         STAMP(2);
@@ -233,7 +237,7 @@ __device__ inline void step_core2(const CagymDev& D, const Lds2& W, LaneCtx& C, 
                 const OrcaEgo E = orca_ego(A, D.dt);
                 const int nn = (C.n - 1) < CAGYM_MAXNB ? (C.n - 1) : CAGYM_MAXNB;
                 float nvx, nvy;
-                const int fail = orca_lp2_unrolled(W.sorted, tid, nn, E.max_speed, E.pvx, E.pvy, nvx, nvy);
+                const int fail = orca_lp2_unrolled(W.sorted, tid, nn, E.max_speed, E.pvx, E.pvy, nvx, nvy, AS);
                 W.lpv[tid] = make_float2(nvx, nvy);
                 W.lpk[tid] = fail;
                 W.lpr[tid] = E.max_speed;
@@ -257,7 +261,7 @@ __device__ inline void step_core2(const CagymDev& D, const Lds2& W, LaneCtx& C, 
                     const int n = W.wn[wl];
                     const int nn = (n - 1) < CAGYM_MAXNB ? (n - 1) : CAGYM_MAXNB;
                     float2 v = W.lpv[a];
-                    orca_lp3_group(W.sorted, W.proj, a, j, nn, W.lpk[a], W.lpr[a], v.x, v.y);
+                    orca_lp3_group(W.sorted, W.proj, a, j, nn, W.lpk[a], W.lpr[a], v.x, v.y, AS);
                     if (j == 0) W.lpv[a] = v;
                 }
             }
@@ -495,13 +499,13 @@ __device__ inline void step_core2(const CagymDev& D, const Lds2& W, LaneCtx& C, 
     // the next S0 barrier orders these staging reads before the union is rewritten
 }
 
-template <int NT, int MT, bool AUTO_RESET>
+template <int NT, int MT, int WPWT, bool AUTO_RESET>
 __global__ void __launch_bounds__(NT, (NT <= 256 ? 3 : 2)) k_rollout2(CagymDev D, int n_steps, CagymOut out, int any_rvo) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int M = MT ? MT : D.M;
-    Lds2 W = carve_lds2(smem, M);
-    LaneCtx C = make_ctx2(D, M);
-    const bool agent_lane = threadIdx.x < CAGYM_WAVE;
+    Lds2 W = carve_lds2(smem, M, cagym_as(M, WPWT));
+    LaneCtx C = make_ctx2(D, M, WPWT ? WPWT : CAGYM_WAVE / M);
+    const bool agent_lane = (int)threadIdx.x < C.wpw * M;
     const size_t aidx = (size_t)C.world * M + C.slot;
     float ep_ret = 0.f;
     int ep_len = 0;
@@ -525,7 +529,7 @@ __global__ void __launch_bounds__(NT, (NT <= 256 ? 3 : 2)) k_rollout2(CagymDev D
         o.reward = out.reward ? out.reward + (size_t)t * NM : nullptr;
         o.flags = out.flags ? out.flags + (size_t)t * NM : nullptr;
         o.game_over = out.game_over ? out.game_over + (size_t)t * D.N : nullptr;
-        step_core2<NT, MT, AUTO_RESET>(D, W, C, nullptr, o, ep_ret, ep_len, any_rvo != 0);
+        step_core2<NT, MT, WPWT, AUTO_RESET>(D, W, C, nullptr, o, ep_ret, ep_len, any_rvo != 0);
     }
     if (C.valid) {
         const Agent A = lds_load_agent(W, threadIdx.x);  // own lane's record: no barrier needed
@@ -539,13 +543,13 @@ __global__ void __launch_bounds__(NT, (NT <= 256 ? 3 : 2)) k_rollout2(CagymDev D
     }
 }
 
-template <int NT, int MT>
+template <int NT, int MT, int WPWT>
 __global__ void __launch_bounds__(NT) k_step2(CagymDev D, const float* ext, CagymOut out, int any_rvo) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int M = MT ? MT : D.M;
-    Lds2 W = carve_lds2(smem, M);
-    LaneCtx C = make_ctx2(D, M);
-    const bool agent_lane = threadIdx.x < CAGYM_WAVE;
+    Lds2 W = carve_lds2(smem, M, cagym_as(M, WPWT));
+    LaneCtx C = make_ctx2(D, M, WPWT ? WPWT : CAGYM_WAVE / M);
+    const bool agent_lane = (int)threadIdx.x < C.wpw * M;
     const size_t aidx = (size_t)C.world * M + C.slot;
     float ep_ret = 0.f;
     int ep_len = 0;
@@ -559,7 +563,7 @@ __global__ void __launch_bounds__(NT) k_step2(CagymDev D, const float* ext, Cagy
         lds_store_agent(W, A, threadIdx.x);
         if (C.wl < C.wpw && C.slot == 0) W.wn[C.wl] = C.valid ? C.n : 0;
     }
-    step_core2<NT, MT, false>(D, W, C, ext, out, ep_ret, ep_len, any_rvo != 0);
+    step_core2<NT, MT, WPWT, false>(D, W, C, ext, out, ep_ret, ep_len, any_rvo != 0);
     if (C.valid) {
         const Agent A = lds_load_agent(W, threadIdx.x);
         store_agent(D, A, aidx, false);

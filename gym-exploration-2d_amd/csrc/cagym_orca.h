@@ -16,15 +16,15 @@
 __device__ __forceinline__ float detf(float ax, float ay, float bx, float by) { return ax * by - ay * bx; }
 
 __device__ inline bool orca_lp1(const float4* L, int lane, int no, float radius, float ox, float oy, bool dir_opt,
-                                float& rx, float& ry) {
-    float4 ln = L[no * CAGYM_WAVE + lane];
+                                float& rx, float& ry, int stride = CAGYM_WAVE) {
+    float4 ln = L[no * stride + lane];
     float dot = ln.x * ln.z + ln.y * ln.w;
     float disc = dot * dot + radius * radius - (ln.x * ln.x + ln.y * ln.y);
     if (disc < 0.0f) return false;
     float sq = sqrtf(disc);
     float tl = -dot - sq, tr = -dot + sq;
     for (int i = 0; i < no; i++) {
-        float4 li = L[i * CAGYM_WAVE + lane];
+        float4 li = L[i * stride + lane];
         float den = detf(ln.z, ln.w, li.z, li.w);
         float num = detf(li.z, li.w, ln.x - li.x, ln.y - li.y);
         if (fabsf(den) <= RVO_EPS) {
@@ -50,7 +50,7 @@ __device__ inline bool orca_lp1(const float4* L, int lane, int no, float radius,
 }
 
 __device__ inline int orca_lp2(const float4* L, int lane, int n, float radius, float ox, float oy, bool dir_opt,
-                               float& rx, float& ry) {
+                               float& rx, float& ry, int stride = CAGYM_WAVE) {
     if (dir_opt) {
         rx = ox * radius;
         ry = oy * radius;
@@ -63,10 +63,10 @@ __device__ inline int orca_lp2(const float4* L, int lane, int n, float radius, f
         ry = oy;
     }
     for (int i = 0; i < n; i++) {
-        float4 li = L[i * CAGYM_WAVE + lane];
+        float4 li = L[i * stride + lane];
         if (detf(li.z, li.w, li.x - rx, li.y - ry) > 0.0f) {
             float tx = rx, ty = ry;
-            if (!orca_lp1(L, lane, i, radius, ox, oy, dir_opt, rx, ry)) {
+            if (!orca_lp1(L, lane, i, radius, ox, oy, dir_opt, rx, ry, stride)) {
                 rx = tx;
                 ry = ty;
                 return i;
@@ -257,10 +257,10 @@ __device__ inline void orca_action(const NbrTile& T, float4* L, float4* P, int l
 // the i independent (den, num, t) triples of line i then overlap instead of forming a chain of dependent LDS
 // reads and divisions.  Results are identical to orca_lp2/orca_lp1 (checked bitwise against generation 1).
 __device__ inline int orca_lp2_unrolled(const float4* L, int lane, int n, float radius, float ox, float oy, float& rx,
-                                        float& ry) {
+                                        float& ry, int stride = CAGYM_WAVE) {
     float4 ln[CAGYM_MAXNB];
 #pragma unroll
-    for (int i = 0; i < CAGYM_MAXNB; i++) ln[i] = L[i * CAGYM_WAVE + lane];  // slots >= n: stale but in bounds, unused
+    for (int i = 0; i < CAGYM_MAXNB; i++) ln[i] = L[i * stride + lane];  // slots >= n: stale but in bounds, unused
     if (ox * ox + oy * oy > radius * radius) {
         float inv = 1.0f / sqrtf(ox * ox + oy * oy);
         rx = ox * inv * radius;
@@ -333,17 +333,17 @@ __device__ __forceinline__ float grp16_min(float v) {
 }
 
 __device__ inline void orca_lp3_group(const float4* L, float4* P, int a, int j, int nn, int begin, float radius,
-                                      float& rx, float& ry) {
+                                      float& rx, float& ry, int stride = CAGYM_WAVE) {
     const int gbase = (threadIdx.x & 63) & ~15;
     float distance = 0.0f;
     for (int i = begin; i < nn; i++) {
-        const float4 li = L[i * CAGYM_WAVE + a];
+        const float4 li = L[i * stride + a];
         if (!(detf(li.z, li.w, li.x - rx, li.y - ry) > distance)) continue;
         // projected line of lane j (j < i); `have` = it exists (not "parallel, same direction")
         bool have = false;
         float4 pj = make_float4(0.f, 0.f, 0.f, 0.f);
         if (j < i) {
-            const float4 lj = L[j * CAGYM_WAVE + a];
+            const float4 lj = L[j * stride + a];
             const float d = detf(li.z, li.w, lj.z, lj.w);
             have = true;
             if (fabsf(d) <= RVO_EPS) {
@@ -359,7 +359,7 @@ __device__ inline void orca_lp3_group(const float4* L, float4* P, int a, int j, 
             const float inv = 1.0f / sqrtf(ddx * ddx + ddy * ddy);
             pj.z = ddx * inv;
             pj.w = ddy * inv;
-            if (have) P[j * CAGYM_WAVE + a] = pj;
+            if (have) P[j * stride + a] = pj;
         }
         const uint32_t hmask = (uint32_t)((__ballot(have) >> gbase) & 0xffffull);
         const float ox = -li.w, oy = li.z;
@@ -368,7 +368,7 @@ __device__ inline void orca_lp3_group(const float4* L, float4* P, int a, int j, 
         bool failed = false;
         for (int k = 0; k < i && !failed; k++) {
             if (!((hmask >> k) & 1u)) continue;
-            const float4 pk = P[k * CAGYM_WAVE + a];
+            const float4 pk = P[k * stride + a];
             if (!(detf(pk.z, pk.w, pk.x - qx, pk.y - qy) > 0.0f)) continue;
             // linearProgram1(k), directionOpt
             const float dot = pk.x * pk.z + pk.y * pk.w;
