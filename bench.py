@@ -151,6 +151,12 @@ def main():
         launch_ms = dev_ms / launches
         balg = B_ALG[args.policy]
         achieved = balg * N * M * steps_per_launch / (launch_ms * 1e-3) / 1e9
+        # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate
+        # rocprofv3 --pmc passes; profiles/r1/bench_4096x10_rvo_pmc_hbm.txt): 425.0 B per agent-step, measured on
+        # this workload at 64 steps per launch; not re-measured live, so null for any other shape.
+        traffic = None
+        if (N, M, args.policy, args.per_step_launch) == (4096, 10, "rvo", False) and steps_per_launch == 64:
+            traffic = 425.0 * N * M * steps_per_launch / (launch_ms * 1e-3) / 1e9  # GB/s, comparable to `achieved`
         line = {
             "metric": "env-steps/sec (whole node), 4096 worlds x 10 agents",
             "value": value, "unit": "env-steps/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
@@ -164,8 +170,8 @@ def main():
                        "parallelism": "worlds sharded x%d, no data-path collective" % world_size},
             "agent_steps_per_s": value * M,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_step2+k_reset" if args.per_step_launch else "k_rollout2<256, 10, true>",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "k_step2+k_reset" if args.per_step_launch else "k_rollout2<256, 10, 5, true>",
                          "launch_ms": launch_ms, "alg_bytes_per_agent_step": balg},
             "episodes": st,
         }
