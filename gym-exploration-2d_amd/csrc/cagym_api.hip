@@ -74,14 +74,20 @@ CagymOut to_out(const cagym_outputs* o) {
 #define WPW10 5 /* worlds per workgroup of the M = 10 specialisation: 500 pair slots = 2 rounds of 256 lanes */
 #endif
 
+// worlds per workgroup of the compile-time specialisations (0 = generic: 64 / M worlds, LDS stride 64)
+//   M = 4 : 16 worlds, 256 pair slots = 1 round of 256 lanes
+//   M = 10:  5 worlds, 500 pair slots = 2 rounds of 256 lanes, 4 workgroups per CU
+//   M = 20:  2 worlds, 800 pair slots = 2 rounds of 512 lanes
+#define WPW20 2
+inline int wpw_spec(int M) { return M == 10 ? WPW10 : (M == 20 ? WPW20 : 0); }
 inline int n_wg2(const Env* e) {
     const int M = e->cfg.max_agents;
-    const int wpw = M == 10 ? WPW10 : CAGYM_WAVE / M;
+    const int wpw = wpw_spec(M) ? wpw_spec(M) : CAGYM_WAVE / M;
     return (e->cfg.n_worlds + wpw - 1) / wpw;
 }
 inline size_t lds2_bytes(const Env* e) {
     const int M = e->cfg.max_agents;
-    return cagym_lds2_bytes(M, cagym_as(M, M == 10 ? WPW10 : 0));
+    return cagym_lds2_bytes(M, cagym_as(M, wpw_spec(M)));
 }
 
 inline int n_waves(const Env* e) {
@@ -160,6 +166,12 @@ int cagym_create(const cagym_config* cfg, void** env_out) {
         if (lds2 > 160 * 1024) e->generation = 1;
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<256, 0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<256, 10, WPW10>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<256, 4, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<512, 20, WPW20>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<256, 4, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<256, 4, 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<512, 20, WPW20, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<512, 20, WPW20, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<256, 10, WPW10, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<256, 10, WPW10, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<512, 0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
@@ -265,6 +277,8 @@ int cagym_step(void* env, const float* ext_actions, const cagym_outputs* out, vo
     if (e->generation == 2) {
         const size_t lds2 = lds2_bytes(e);
         if (M == 10) hipLaunchKernelGGL((k_step2<256, 10, WPW10>), dim3(n_wg2(e)), dim3(256), lds2, st, e->D, ext_actions, o, e->any_rvo);
+        else if (M == 4) hipLaunchKernelGGL((k_step2<256, 4, 0>), dim3(n_wg2(e)), dim3(256), lds2, st, e->D, ext_actions, o, e->any_rvo);
+        else if (M == 20) hipLaunchKernelGGL((k_step2<512, 20, WPW20>), dim3(n_wg2(e)), dim3(512), lds2, st, e->D, ext_actions, o, e->any_rvo);
         else if (M <= 12) hipLaunchKernelGGL((k_step2<256, 0, 0>), dim3(n_waves(e)), dim3(256), lds2, st, e->D, ext_actions, o, e->any_rvo);
         else if (M <= 16) hipLaunchKernelGGL((k_step2<512, 0, 0>), dim3(n_waves(e)), dim3(512), lds2, st, e->D, ext_actions, o, e->any_rvo);
         else hipLaunchKernelGGL((k_step2<512, 0, 0>), dim3(n_waves(e)), dim3(512), lds2, st, e->D, ext_actions, o, e->any_rvo);
@@ -295,6 +309,8 @@ int cagym_rollout(void* env, int n_steps, int auto_reset, const cagym_outputs* o
         else hipLaunchKernelGGL((k_rollout2<NT, MT, WP, false>), g, dim3(NT), lds2, st, e->D, n_steps, o, e->any_rvo);         \
     } while (0)
         if (M == 10) ROLL2(256, 10, WPW10);
+        else if (M == 4) ROLL2(256, 4, 0);
+        else if (M == 20) ROLL2(512, 20, WPW20);
         else if (M <= 12) ROLL2(256, 0, 0);
         else ROLL2(512, 0, 0);
 #undef ROLL2
