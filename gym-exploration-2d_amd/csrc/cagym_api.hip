@@ -11,6 +11,7 @@
 #include "cagym_kernels.h"
 #include "cagym_kernels2.h"
 #include "cagym_ig.h"
+#include "cagym_ga3c.h"
 
 namespace {
 
@@ -369,6 +370,19 @@ int cagym_debug_stamps(unsigned long long* out16, int reset) {
     return 0;
 }
 #endif
+
+int cagym_ga3c_forward(void* env, const float* weights, const float* state, const int32_t* agent_idx, int B,
+                       float* ext_actions, int32_t* action_index, float* probs, void* stream) {
+    Env* e = reinterpret_cast<Env*>(env);
+    if (!e) return fail(nullptr, CAGYM_E_INVALID, "null env");
+    if (!weights || !state || !agent_idx || B < 0) return fail(e, CAGYM_E_INVALID, "bad arguments");
+    if (B == 0) return CAGYM_OK;
+    hipLaunchKernelGGL(k_ga3c_forward, dim3((unsigned)((B + GA_AG - 1) / GA_AG)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), weights, state, agent_idx, B, e->D.pref, ext_actions,
+                       action_index, probs);
+    HIPCHK(e, hipGetLastError());
+    return CAGYM_OK;
+}
 
 // ---- information-gain primitives -----------------------------------------------------------------
 static int ig_check(Env* e, const char* what) {

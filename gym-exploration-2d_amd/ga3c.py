@@ -1,10 +1,10 @@
-"""GA3C-CADRL policy on device: state-vector kernel (cagym_ga3c_state) + the network forward pass.
+"""GA3C-CADRL policy on device: state-vector kernel (cagym_ga3c_state) + fused forward kernel
+(cagym_ga3c_forward: normalisation, LSTM-64, 3 x FC-256, logits, argmax, action table in ONE launch).
 
 Replaces policies/GA3CCADRLPolicy.py:34-43 and GA3C_CADRL/network.py:65-98 (TensorFlow 1.15 session.run per
-agent) by one batched forward over every GA3C agent of every world.  The GEMMs are plain library GEMMs
-(torch -> hipBLASLt/rocBLAS, fp32 like the reference's TF graph); weights come from the converted checkpoint
-(tools/convert_ga3c_checkpoint.py -> weights/ga3c_cadrl_*.npz).  TF1 LSTMCell conventions: gate order
-(i, j, f, o), forget_bias 1.0, input concat[x, h], state frozen beyond sequence_length.
+agent) by one batched forward over every GA3C agent of every world.  Weights come from the converted checkpoint
+(tools/convert_ga3c_checkpoint.py -> weights/ga3c_cadrl_*.npz), packed in the blob order of include/cagym.h.
+`forward_torch` is a plain-torch restatement kept only as a numerics reference for the tests.
 """
 import ctypes as C
 import os
@@ -34,6 +34,8 @@ class GA3CCADRLPolicy(object):
         self.b = benv
         self.L = benv.L
         self.L.cagym_ga3c_state.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        self.L.cagym_ga3c_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                              C.c_void_p, C.c_void_p, C.c_void_p]
         path = checkpoint if os.path.exists(checkpoint) else os.path.join(HERE, "weights", "ga3c_cadrl_%s.npz" % checkpoint)
         W = np.load(path)
         dev = benv.device
@@ -43,7 +45,12 @@ class GA3CCADRLPolicy(object):
         self.table = torch.from_numpy(action_table()).to(dev)
         self.max_observed = int(max_observed if max_observed is not None else min(benv.M - 1, 10))
         self.state = torch.zeros((benv.N, benv.M, 76), dtype=torch.float32, device=dev)
-        self._is_ga3c = None
+        order = ["lstm_kernel", "lstm_bias", "l1_kernel", "l1_bias", "l2_kernel", "l2_bias", "fc1_kernel", "fc1_bias",
+                 "logits_kernel", "logits_bias"]
+        self.blob = torch.cat([self.W[k].reshape(-1) for k in order]).contiguous()
+        assert self.blob.numel() == 170507
+        self._idx = None
+        self._idx_episode = None
 
     def states(self):
         with torch.cuda.device(self.b.device):
@@ -51,8 +58,35 @@ class GA3CCADRLPolicy(object):
         _lib.check(self.L, self.b.h, rc, "cagym_ga3c_state")
         return self.state
 
-    def forward(self, x75):
-        """softmax_p [B, 11] for NN inputs x75 [B, 75] (= state[..., 1:])."""
+    def agent_index(self):
+        """Flat indices (world * M + slot) of the agents whose policy id is POLICY_GA3C.  Recomputed (one small
+        device->host sync) only when some world has started a new episode since the last call."""
+        b = self.b
+        ep = b.state()["episode"]
+        if self._idx is None or not torch.equal(ep, self._idx_episode):
+            status = b.state()["status"]
+            flag = (((status >> 8) & 15) == sc.POLICY_GA3C) & ((status & _lib.FLAG_ACTIVE) != 0)
+            self._idx = flag.reshape(-1).nonzero(as_tuple=True)[0].to(torch.int32).contiguous()
+            self._idx_episode = ep.clone()
+        return self._idx
+
+    def forward(self, state_rows=None, agent_idx=None, ext_actions=None, want_probs=False):
+        """Fused forward kernel over `agent_idx` rows of `state_rows` ([*, 76]); returns (action_index, probs)."""
+        b = self.b
+        st = self.state if state_rows is None else state_rows.contiguous()
+        idx = self.agent_index() if agent_idx is None else agent_idx.to(torch.int32).contiguous()
+        Bn = int(idx.numel())
+        act = torch.empty((Bn,), dtype=torch.int32, device=b.device)
+        probs = torch.empty((Bn, 11), dtype=torch.float32, device=b.device) if want_probs else None
+        with torch.cuda.device(b.device):
+            rc = self.L.cagym_ga3c_forward(b.h, self.blob.data_ptr(), st.data_ptr(), idx.data_ptr(), Bn,
+                                           None if ext_actions is None else ext_actions.data_ptr(), act.data_ptr(),
+                                           None if probs is None else probs.data_ptr(), b._stream())
+        _lib.check(self.L, b.h, rc, "cagym_ga3c_forward")
+        return act, probs
+
+    def forward_torch(self, x75):
+        """Numerics reference only: softmax_p [B, 11] for NN inputs x75 [B, 75] (= state[..., 1:])."""
         W = self.W
         x = x75.float()
         xn = (x - self.avg) / self.std
@@ -81,14 +115,7 @@ class GA3CCADRLPolicy(object):
         b = self.b
         if ext_actions is None:
             ext_actions = torch.zeros((b.N, b.M, 2), dtype=torch.float32, device=b.device)
-        st = self.states()
-        status = b.state()["status"]
-        is_ga3c = ((status >> 8) & 15) == sc.POLICY_GA3C
-        idx = is_ga3c.reshape(-1).nonzero(as_tuple=True)[0]
-        if idx.numel():
-            s = st.reshape(-1, 76)[idx]
-            p = self.forward(s[:, 1:])
-            a = self.table[p.argmax(dim=1)]
-            act = torch.stack([s[:, 4].double() * a[:, 0], a[:, 1]], dim=1).float()
-            ext_actions.reshape(-1, 2)[idx] = act
+        ext_actions = ext_actions.contiguous()
+        self.states()
+        self.forward(ext_actions=ext_actions)
         return ext_actions

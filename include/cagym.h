@@ -147,6 +147,17 @@ int cagym_laserscan(void* env, float* laserscan, void* stream);
  * itself (LSTM-64 + 3 x FC-256, network.py:65-98) is evaluated by the host policy on state[:, :, 1:]. */
 int cagym_ga3c_state(void* env, int max_observed, float* state, void* stream);
 
+/* NetworkVP_rnn forward pass (policies/GA3C_CADRL/network.py:65-98) + argmax + action table (network.py:8-17,
+ * GA3CCADRLPolicy.find_next_action :34-43) for the B agents listed in agent_idx (flat world*M + slot), reading
+ * their rows of `state` (cagym_ga3c_state).  weights: DEVICE blob of CAGYM_GA3C_NWEIGHTS floats in the order
+ * lstm kernel [71,256], lstm bias, layer1 kernel [68,256], bias, layer2 kernel [256,256], bias, fullyconnected1
+ * kernel [256,256], bias, logits_p kernel [256,11], bias (TensorFlow [in][out] layout).  Writes
+ * ext_actions[agent] = (pref_speed * a0, a1) (DEVICE [N,M,2] f32); action_index [B] i32 and probs [B,11] f32
+ * (softmax_p) are optional. */
+#define CAGYM_GA3C_NWEIGHTS 170507
+int cagym_ga3c_forward(void* env, const float* weights, const float* state, const int32_t* agent_idx, int B,
+                       float* ext_actions, int32_t* action_index, float* probs, void* stream);
+
 /* ---- information-gain planner primitives (cfg 5).  All pointers DEVICE.  A visibility set is a
  * [60] u64 mask: bit i of word j <=> belief cell (i, j) (x index i, y index j; 0.5 m cells over 30x30 m). ---- */
 
