@@ -106,8 +106,7 @@ def main():
             k = min(ROLL, n_steps - done)
             if args.per_step_launch:
                 for _ in range(k):
-                    _, _, go, _ = env.step()
-                    env.reset(world_mask=go, advance_episode=True)
+                    env.step(auto_reset=True)
                     launches += 1
             else:
                 env.rollout(k, auto_reset=True, out=traj)
@@ -171,7 +170,7 @@ def main():
             "agent_steps_per_s": value * M,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_step2+k_reset" if args.per_step_launch else "k_rollout2<256, 10, 5, true>",
+                         "kernel": "k_step2<.., true>" if args.per_step_launch else "k_rollout2<256, 10, 5, true>",
                          "launch_ms": launch_ms, "alg_bytes_per_agent_step": balg},
             "episodes": st,
         }

@@ -36,7 +36,7 @@ class CagymStatePtrs(C.Structure):
 
 
 EXPORTS = ["cagym_version", "cagym_create", "cagym_destroy", "cagym_last_error", "cagym_set_scenarios",
-           "cagym_reset", "cagym_step", "cagym_rollout", "cagym_get_state", "cagym_laserscan"]
+           "cagym_reset", "cagym_step", "cagym_step_autoreset", "cagym_rollout", "cagym_get_state", "cagym_laserscan"]
 
 _lib = None
 
@@ -61,6 +61,7 @@ def load():
     L.cagym_set_scenarios.argtypes = [C.c_void_p] * 10
     L.cagym_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(CagymOutputs), C.c_void_p]
     L.cagym_step.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(CagymOutputs), C.c_void_p]
+    L.cagym_step_autoreset.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(CagymOutputs), C.c_void_p]
     L.cagym_rollout.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(CagymOutputs), C.c_void_p]
     L.cagym_get_state.argtypes = [C.c_void_p, C.POINTER(CagymStatePtrs)]
     L.cagym_laserscan.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]

@@ -116,12 +116,15 @@ class BatchedCollisionAvoidanceEnv(object):
         _lib.check(self.L, self.h, rc, "cagym_reset")
         return self._obs()
 
-    def step(self, actions=None):
+    def step(self, actions=None, auto_reset=False):
+        """One env.step() of every world.  auto_reset=True: finished worlds restart inside the same launch
+        (VecEnv semantics: the returned observation is the first one of the new episode)."""
         a = None
         if actions is not None:
             a = torch.as_tensor(actions, device=self.device).to(torch.float32).reshape(self.N, self.M, 2).contiguous()
         with torch.cuda.device(self.device):
-            rc = self.L.cagym_step(self.h, None if a is None else a.data_ptr(), C.byref(self._out), self._stream())
+            fn = self.L.cagym_step_autoreset if auto_reset else self.L.cagym_step
+            rc = fn(self.h, None if a is None else a.data_ptr(), C.byref(self._out), self._stream())
         _lib.check(self.L, self.h, rc, "cagym_step")
         return self._obs(), self.reward, self.game_over, {"flags": self.flags}
 

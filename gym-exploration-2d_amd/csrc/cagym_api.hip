@@ -165,18 +165,24 @@ int cagym_create(const cagym_config* cfg, void** env_out) {
         if (g && (!strcmp(g, "v1") || !strcmp(g, "1"))) e->generation = 1;
         int lds2 = (int)lds2_bytes(e);
         if (lds2 > 160 * 1024) e->generation = 1;
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<256, 0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<256, 10, WPW10>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<256, 4, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<512, 20, WPW20>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<256, 0, 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<256, 10, WPW10, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<256, 4, 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<512, 20, WPW20, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<256, 4, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<256, 4, 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<512, 20, WPW20, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<512, 20, WPW20, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<256, 10, WPW10, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<256, 10, WPW10, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<512, 0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<512, 0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<512, 0, 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<256, 0, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<256, 10, WPW10, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<256, 4, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<512, 20, WPW20, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<512, 0, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<512, 0, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<512, 0, 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<256, 0, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<512, 0, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<512, 0, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
@@ -277,14 +283,36 @@ int cagym_step(void* env, const float* ext_actions, const cagym_outputs* out, vo
     const int M = e->cfg.max_agents;
     if (e->generation == 2) {
         const size_t lds2 = lds2_bytes(e);
-        if (M == 10) hipLaunchKernelGGL((k_step2<256, 10, WPW10>), dim3(n_wg2(e)), dim3(256), lds2, st, e->D, ext_actions, o, e->any_rvo);
-        else if (M == 4) hipLaunchKernelGGL((k_step2<256, 4, 0>), dim3(n_wg2(e)), dim3(256), lds2, st, e->D, ext_actions, o, e->any_rvo);
-        else if (M == 20) hipLaunchKernelGGL((k_step2<512, 20, WPW20>), dim3(n_wg2(e)), dim3(512), lds2, st, e->D, ext_actions, o, e->any_rvo);
-        else if (M <= 12) hipLaunchKernelGGL((k_step2<256, 0, 0>), dim3(n_waves(e)), dim3(256), lds2, st, e->D, ext_actions, o, e->any_rvo);
-        else if (M <= 16) hipLaunchKernelGGL((k_step2<512, 0, 0>), dim3(n_waves(e)), dim3(512), lds2, st, e->D, ext_actions, o, e->any_rvo);
-        else hipLaunchKernelGGL((k_step2<512, 0, 0>), dim3(n_waves(e)), dim3(512), lds2, st, e->D, ext_actions, o, e->any_rvo);
+        if (M == 10) hipLaunchKernelGGL((k_step2<256, 10, WPW10, false>), dim3(n_wg2(e)), dim3(256), lds2, st, e->D, ext_actions, o, e->any_rvo);
+        else if (M == 4) hipLaunchKernelGGL((k_step2<256, 4, 0, false>), dim3(n_wg2(e)), dim3(256), lds2, st, e->D, ext_actions, o, e->any_rvo);
+        else if (M == 20) hipLaunchKernelGGL((k_step2<512, 20, WPW20, false>), dim3(n_wg2(e)), dim3(512), lds2, st, e->D, ext_actions, o, e->any_rvo);
+        else if (M <= 12) hipLaunchKernelGGL((k_step2<256, 0, 0, false>), dim3(n_waves(e)), dim3(256), lds2, st, e->D, ext_actions, o, e->any_rvo);
+        else if (M <= 16) hipLaunchKernelGGL((k_step2<512, 0, 0, false>), dim3(n_waves(e)), dim3(512), lds2, st, e->D, ext_actions, o, e->any_rvo);
+        else hipLaunchKernelGGL((k_step2<512, 0, 0, false>), dim3(n_waves(e)), dim3(512), lds2, st, e->D, ext_actions, o, e->any_rvo);
     } else
     hipLaunchKernelGGL(k_step, dim3(n_waves(e)), dim3(64), cagym_lds_bytes(e->cfg.max_agents), st, e->D, ext_actions, o);
+    HIPCHK(e, hipGetLastError());
+    if (e->cfg.laserscan && o.laserscan) return cagym_laserscan(env, o.laserscan, stream);
+    return CAGYM_OK;
+}
+
+int cagym_step_autoreset(void* env, const float* ext_actions, const cagym_outputs* out, void* stream) {
+    Env* e = reinterpret_cast<Env*>(env);
+    if (!e) return fail(nullptr, CAGYM_E_INVALID, "null env");
+    if (!e->scenarios_set) return fail(e, CAGYM_E_STATE, "cagym_step_autoreset before cagym_set_scenarios");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    CagymOut o = to_out(out);
+    const int M = e->cfg.max_agents;
+    if (e->generation == 2) {
+        const size_t lds2 = lds2_bytes(e);
+        if (M == 10) hipLaunchKernelGGL((k_step2<256, 10, WPW10, true>), dim3(n_wg2(e)), dim3(256), lds2, st, e->D, ext_actions, o, e->any_rvo);
+        else if (M == 4) hipLaunchKernelGGL((k_step2<256, 4, 0, true>), dim3(n_wg2(e)), dim3(256), lds2, st, e->D, ext_actions, o, e->any_rvo);
+        else if (M == 20) hipLaunchKernelGGL((k_step2<512, 20, WPW20, true>), dim3(n_wg2(e)), dim3(512), lds2, st, e->D, ext_actions, o, e->any_rvo);
+        else if (M <= 12) hipLaunchKernelGGL((k_step2<256, 0, 0, true>), dim3(n_waves(e)), dim3(256), lds2, st, e->D, ext_actions, o, e->any_rvo);
+        else if (M <= 16) hipLaunchKernelGGL((k_step2<512, 0, 0, true>), dim3(n_waves(e)), dim3(512), lds2, st, e->D, ext_actions, o, e->any_rvo);
+        else hipLaunchKernelGGL((k_step2<512, 0, 0, true>), dim3(n_waves(e)), dim3(512), lds2, st, e->D, ext_actions, o, e->any_rvo);
+    } else
+        return fail(e, CAGYM_E_UNSUPPORTED, "cagym_step_autoreset needs the generation-2 kernels");
     HIPCHK(e, hipGetLastError());
     if (e->cfg.laserscan && o.laserscan) return cagym_laserscan(env, o.laserscan, stream);
     return CAGYM_OK;

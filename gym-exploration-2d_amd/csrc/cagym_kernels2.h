@@ -543,7 +543,7 @@ __global__ void __launch_bounds__(NT, (NT <= 256 ? 3 : 2)) k_rollout2(CagymDev D
     }
 }
 
-template <int NT, int MT, int WPWT>
+template <int NT, int MT, int WPWT, bool AUTO_RESET>
 __global__ void __launch_bounds__(NT) k_step2(CagymDev D, const float* ext, CagymOut out, int any_rvo) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int M = MT ? MT : D.M;
@@ -563,10 +563,17 @@ __global__ void __launch_bounds__(NT) k_step2(CagymDev D, const float* ext, Cagy
         lds_store_agent(W, A, threadIdx.x);
         if (C.wl < C.wpw && C.slot == 0) W.wn[C.wl] = C.valid ? C.n : 0;
     }
-    step_core2<NT, MT, WPWT, false>(D, W, C, ext, out, ep_ret, ep_len, any_rvo != 0);
+    step_core2<NT, MT, WPWT, AUTO_RESET>(D, W, C, ext, out, ep_ret, ep_len, any_rvo != 0);
     if (C.valid) {
         const Agent A = lds_load_agent(W, threadIdx.x);
-        store_agent(D, A, aidx, false);
-        if (C.slot == 0) { D.ep_return[C.world] = ep_ret; D.ep_len[C.world] = ep_len; }
+        store_agent(D, A, aidx, AUTO_RESET);
+        if (C.slot == 0) {
+            D.ep_return[C.world] = ep_ret;
+            D.ep_len[C.world] = ep_len;
+            if (AUTO_RESET) {
+                D.episode[C.world] = C.episode;
+                D.n_agents[C.world] = C.n;
+            }
+        }
     }
 }

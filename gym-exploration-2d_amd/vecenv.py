@@ -88,12 +88,9 @@ class CagymVecEnv(object):
 
     def step_wait(self):
         b = self.b
-        _, rew, go, info = b.step(self._actions)
-        rews = rew[:, 0].clone() if self.single_agent else rew.clone()
-        dones = go.bool().clone()
-        flags = info["flags"].clone()
-        b.reset(world_mask=go, advance_episode=True)  # masked: finished worlds only (DummyVecEnv auto-reset)
-        return self.flat(), rews, dones, {"flags": flags}
+        _, rew, go, info = b.step(self._actions, auto_reset=True)  # DummyVecEnv auto-reset inside the launch
+        rews = rew[:, 0] if self.single_agent else rew
+        return self.flat(), rews, go.bool(), {"flags": info["flags"]}
 
     def step(self, actions):
         self.step_async(actions)

@@ -128,6 +128,12 @@ int cagym_reset(void* env, const uint8_t* world_mask, int advance_episode, const
  * _check_which_agents_done.  ext_actions DEVICE [N,M,2] f32 or NULL (all agents internal, env_utils.py:46). */
 int cagym_step(void* env, const float* ext_actions, const cagym_outputs* out, void* stream);
 
+/* cagym_step followed, in the same launch, by DummyVecEnv's auto-reset (exp/env_utils.py:29-31): a world whose
+ * game_over fires restarts on its next scenario, its episode statistics are folded, and the observation written
+ * for this step is the first one of the new episode (reward / flags / game_over are the terminal ones).
+ * Does not produce laserscan for the restarted worlds' first observation when cfg.laserscan (call cagym_laserscan). */
+int cagym_step_autoreset(void* env, const float* ext_actions, const cagym_outputs* out, void* stream);
+
 /* n_steps consecutive step() calls in ONE launch for worlds whose agents are all driven internally
  * (Static / NonCooperative / RVO): state stays in registers, every step writes its outputs to slice
  * t of `out` ([T, ...] buffers; T = n_steps).  auto_reset != 0: a world whose game_over fires is

@@ -209,3 +209,43 @@ def test_generation1_and_generation2_kernels_agree_bitwise(M, monkeypatch):
         assert torch.equal(s1[k], s2[k]), k
     assert torch.equal(o1, o2) and torch.equal(r1, r2)
     assert int(s1["stat_episodes"].sum()) > 0
+
+
+def test_step_autoreset_equals_rollout_and_graph_replay():
+    """cagym_step_autoreset (one launch per step, reset inside) == cagym_rollout, eagerly and replayed from a
+    captured HIP graph (no host sync or allocation inside the step entry points)."""
+    import torch
+    N, M, T = 40, 10, 260
+    a6 = scen.random_worlds_fast(3 * N, M, seed=15)
+    mk = lambda: _hip(N=N, M=M, game_over_mode=1, n_scenarios=3 * N)
+    envs = [mk(), mk(), mk()]
+    for e in envs:
+        e.set_scenario(a6, scen.POLICY_RVO, scen.DYN_UNICYCLE, coop=np.full((3 * N, M), 0.5))
+        e.reset()
+    a, b, c = (e.env for e in envs)
+    traj = a.rollout(T, auto_reset=True)
+    # eager single launches
+    for t in range(T):
+        obs, rew, go, info = b.step(auto_reset=True)
+        assert torch.equal(traj["reward"][t], rew) and torch.equal(traj["game_over"][t], go), t
+        assert torch.equal(traj["other_agents_states"][t], b.obs_oas) and torch.equal(traj["ego"][t], b.obs_ego), t
+    # graph replay
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        c.step(auto_reset=True)  # warm-up launch on the side stream (step 0)
+    torch.cuda.current_stream().wait_stream(s)
+    assert torch.equal(traj["reward"][0], c.reward)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        c.step(auto_reset=True)
+    # the capture itself does not execute the step
+    for t in range(1, T):
+        g.replay()
+        assert torch.equal(traj["reward"][t], c.reward), t
+        assert torch.equal(traj["other_agents_states"][t], c.obs_oas), t
+    torch.cuda.synchronize()
+    for k in ("stat_episodes", "stat_steps", "stat_outcomes", "stat_return"):
+        assert torch.equal(a.episode_stats()[k], b.episode_stats()[k]) and torch.equal(a.episode_stats()[k], c.episode_stats()[k]), k
+    assert int(a.episode_stats()["stat_episodes"].sum()) > 0
