@@ -520,7 +520,7 @@ int cagym_ig_next_pose(void* env, const double* poses, const double* actions, co
 int cagym_ig_rollouts(void* env, const double* pose0, const uint64_t* observed0, const uint64_t* exclude,
                       const int32_t* world, const int32_t* n_steps, const double* radius, int Q, int nsims,
                       int max_steps, int xdt, double dt, double fov_rad, double range, uint64_t seed, double* rewards,
-                      uint8_t* actions, double* final_pose, void* stream) {
+                      uint8_t* actions, double* final_pose, uint64_t* observed_out, void* stream) {
     Env* e = reinterpret_cast<Env*>(env);
     int rc = ig_check(e, "cagym_ig_rollouts");
     if (rc) return rc;
@@ -532,7 +532,8 @@ int cagym_ig_rollouts(void* env, const double* pose0, const uint64_t* observed0,
                        reinterpret_cast<hipStream_t>(stream), e->G, pose0,
                        reinterpret_cast<const unsigned long long*>(observed0),
                        reinterpret_cast<const unsigned long long*>(exclude), world, n_steps, radius, nsims, max_steps, xdt,
-                       dt, fov_rad, range, (unsigned long long)seed, rewards, actions, final_pose);
+                       dt, fov_rad, range, (unsigned long long)seed, rewards, actions, final_pose,
+                       reinterpret_cast<unsigned long long*>(observed_out));
     HIPCHK(e, hipGetLastError());
     return CAGYM_OK;
 }

@@ -306,7 +306,7 @@ __global__ void __launch_bounds__(128) k_ig_rollouts(IgDev G, const double* pose
                                                      const int32_t* n_steps, const double* radius, int nsims,
                                                      int max_steps, int xdt, double dt, double fov, double range,
                                                      unsigned long long seed, double* rewards, uint8_t* actions,
-                                                     double* final_pose) {
+                                                     double* final_pose, unsigned long long* observed_out) {
     __shared__ unsigned long long vis[IG_BEL];
     __shared__ unsigned long long obs[IG_BEL];
     __shared__ double red[128];
@@ -331,6 +331,8 @@ __global__ void __launch_bounds__(128) k_ig_rollouts(IgDev G, const double* pose
         }
         if (tid == 0 && actions) actions[((size_t)q * nsims + sim) * max_steps + t] = ok ? (uint8_t)k : (uint8_t)255;
     }
+    if (observed_out)  // cells observed along this roll-out (incl. observed0), BEFORE other robots' cells are removed
+        for (int j = tid; j < IG_BEL; j += blockDim.x) observed_out[((size_t)q * nsims + sim) * IG_BEL + j] = obs[j];
     for (int j = tid; j < IG_BEL; j += blockDim.x) obs[j] &= ~exclude[(size_t)q * IG_BEL + j];
     __syncthreads();
     double r = ig_reward_block(G.belief + (size_t)w * IG_BEL * IG_BEL, obs, red, tid, blockDim.x);

@@ -1,0 +1,182 @@
+"""Dec-MCTS planner on top of the information-gain device primitives.
+
+Tree bookkeeping (UCT selection, expansion, discounted back-propagation, exchange of action distributions
+between the IG agents of a world) stays on the host, as the build plan prescribes for this stage; every
+geometric / reward evaluation -- motion primitives, visible-cell sets, random roll-outs, mutual-information
+rewards -- is a batched call into the backend (gym-exploration-2d_amd.ig.InfoGain on the GPU).
+
+Reference behaviour restated (paths under gym_collision_avoidance/envs/policies/):
+  pydecmcts/DecMCTS.py:14-18   _UCT = mu_j + 2 c_p sqrt(2 ln n_p / n_j), inf for unvisited children
+  pydecmcts/DecMCTS.py:92-138  Tree.__init__: root node + expansion of the root
+  pydecmcts/DecMCTS.py:162-180 _update_distribution: top comm_n nodes by mu, q = mu^2
+  pydecmcts/DecMCTS.py:182-194 _get_system_state: one sampled plan per other robot
+  pydecmcts/DecMCTS.py:201-231 _expansion: one child per FEASIBLE motion primitive, none at the horizon
+  pydecmcts/DecMCTS.py:273-360 grow: select, expand, nsims roll-outs from the selected node, mu = mean reward,
+                               N = 1, discounted back-propagation, best roll-out kept per node
+  ig_mcts.py:79-109            find_next_action: per env step a new tree; per cycle receive the other robots'
+                               distributions, grow Ntree times, publish; action = first action of the best path
+  ig_mcts.py:234-241           mcts_reward = MI(own observed cells minus cells observed in the sampled plans of
+                               the other robots) on the current belief
+Random numbers come from a seeded numpy Generator (plan sampling) and the counter-based device RNG (roll-outs);
+the reference uses the global np.random stream, so only statistical agreement is possible.
+"""
+import math
+
+import numpy as np
+
+PRIMITIVES = np.array([[v, w] for v in (0.0, 2.0, 4.0) for w in (-0.5 * np.pi, 0.0, 0.5 * np.pi)])  # ig_mcts.py:247-253
+
+
+class _Node(object):
+    __slots__ = ("parent", "children", "pose", "observed", "actions", "stage", "mu", "N", "best_reward", "best_actions",
+                 "best_observed", "has_rollout")
+
+    def __init__(self, parent, pose, observed, actions, stage):
+        self.parent, self.children = parent, []
+        self.pose, self.observed, self.actions, self.stage = pose, observed, actions, stage
+        self.mu, self.N, self.best_reward = 0.0, 0.0, 0.0
+        self.best_actions, self.best_observed, self.has_rollout = None, None, False
+
+
+class _Tree(object):
+    """One robot's tree (DecMCTS.Tree) for one world."""
+
+    def __init__(self, pose, horizon, c_p, comm_n):
+        self.root = _Node(None, np.asarray(pose, dtype=np.float64), np.zeros(60, dtype=np.uint64), [], 0)
+        self.horizon, self.c_p, self.comm_n = horizon, c_p, comm_n
+        self.nodes = [self.root]
+        self.comms = {}  # robot -> list of (observed mask, q)
+        # my_act_dist starts as the root state alone (DecMCTS.py:136): no actions, nothing observed
+        self.dist = [(self.root.actions, self.root.observed, 1.0)]
+
+    def select(self):
+        node = self.root
+        while node.children:
+            n_p = node.N
+            best, best_u = None, -math.inf
+            for ch in node.children:  # np.argmax: first maximum
+                if ch.N == 0:
+                    u = math.inf
+                else:
+                    # log(n_p) with n_p == 0 raises in the reference only when every child was visited, which
+                    # cannot happen before the parent itself was back-propagated (N >= 1)
+                    u = ch.mu + 2 * self.c_p * (2 * math.log(n_p) / ch.N) ** 0.5 if n_p > 0 else ch.mu
+                if u > best_u:
+                    best, best_u = ch, u
+            node = best
+        return node
+
+    def backprop(self, node, avg, best_reward, best_actions, best_observed, gamma):
+        node.mu, node.best_reward, node.N = avg, best_reward, 1.0
+        node.best_actions, node.best_observed, node.has_rollout = best_actions, best_observed, True
+        while node.parent is not None:
+            node = node.parent
+            node.mu = (gamma * node.mu * node.N + avg) / (node.N + 1)
+            node.N = gamma * node.N + 1
+            if best_reward > node.best_reward:
+                node.best_reward = best_reward
+                node.best_actions, node.best_observed, node.has_rollout = best_actions, best_observed, True
+        # _update_distribution: top comm_n by mu among non-root nodes (stable for ties: first created first)
+        cand = sorted(self.nodes[1:], key=lambda n: -n.mu)[:self.comm_n]
+        cand = [n for n in cand if n.has_rollout]
+        q = np.array([n.mu ** 2 for n in cand], dtype=np.float64)
+        if len(cand) == 0:
+            return
+        q = np.full(len(cand), 1.0 / len(cand)) if q.sum() == 0 else q / q.sum()
+        self.dist = [(n.best_actions, n.best_observed, float(w)) for n, w in zip(cand, q)]
+
+
+class DecMCTSPlanner(object):
+    """Plans for `n_robots` IG agents in each of `n_worlds` worlds.
+
+    backend: object with
+        next_pose(poses[Q,3], prim_idx[Q], world[Q], radius[Q]) -> (next[Q,3], feasible[Q])          (numpy)
+        visible_cells(poses[Q,3], world[Q]) -> masks[Q,60] uint64
+        rollouts(pose0, observed0, exclude, world, n_steps, radius, nsims, seed)
+              -> (rewards[Q,nsims], actions[Q,nsims,H] uint8, observed[Q,nsims,60] uint64)
+    (gym-exploration-2d_amd.ig.InfoGainBackend on the GPU; tests use an adapter over the CPU oracle.)
+    """
+
+    def __init__(self, backend, n_worlds, n_robots, radius=0.5, Ntree=30, Nsims=10, horizon=4, c_p=1.0, gamma=0.95,
+                 Ncycles=5, comm_n=5, seed=0):
+        self.be, self.N, self.R = backend, int(n_worlds), int(n_robots)
+        self.radius, self.Ntree, self.Nsims, self.horizon = float(radius), int(Ntree), int(Nsims), int(horizon)
+        self.c_p, self.gamma, self.Ncycles, self.comm_n = float(c_p), float(gamma), int(Ncycles), int(comm_n)
+        self.rng = np.random.default_rng(seed)
+        self.seed = int(seed)
+        self.calls = 0
+        self.trees = None
+
+    # -- batched helpers -----------------------------------------------------------------------------
+    def _expand(self, leaves):
+        """_expansion for a list of (world, tree, node): children for feasible primitives."""
+        todo = [(w, t, n) for (w, t, n) in leaves if n.stage < t.horizon and not n.children]
+        if not todo:
+            return
+        poses = np.repeat(np.array([n.pose for (_, _, n) in todo]), 9, axis=0)
+        prim = np.tile(np.arange(9), len(todo))
+        world = np.repeat(np.array([w for (w, _, _) in todo], dtype=np.int32), 9)
+        nxt, ok = self.be.next_pose(poses, prim, world, np.full(len(world), self.radius))
+        idx = np.nonzero(ok)[0]
+        vis = self.be.visible_cells(nxt[idx], world[idx]) if len(idx) else np.zeros((0, 60), dtype=np.uint64)
+        for row, k in enumerate(idx):
+            w, t, n = todo[k // 9]
+            child = _Node(n, nxt[k], n.observed | vis[row], n.actions + [int(k % 9)], n.stage + 1)
+            n.children.append(child)
+            t.nodes.append(child)
+
+    def _grow_all(self, robot, trees):
+        """One Tree.grow for robot `robot` in every world (batched roll-outs)."""
+        sel = []
+        for w, t in enumerate(trees):
+            # sample one plan per other robot from its communicated distribution (_get_system_state)
+            excl = np.zeros(60, dtype=np.uint64)
+            for other, dist in t.comms.items():
+                p = np.array([d[2] for d in dist])
+                excl |= dist[self.rng.choice(len(dist), p=p / p.sum())][1]
+            sel.append((w, t, t.select(), excl))
+        self._expand([(w, t, n) for (w, t, n, _) in sel])
+        Q = len(sel)
+        pose0 = np.array([n.pose for (_, _, n, _) in sel])
+        obs0 = np.array([n.observed for (_, _, n, _) in sel])
+        excl = np.array([e for (_, _, _, e) in sel])
+        world = np.array([w for (w, _, _, _) in sel], dtype=np.int32)
+        steps = np.array([t.horizon - n.stage for (_, t, n, _) in sel], dtype=np.int32)
+        self.calls += 1
+        rew, acts, obs = self.be.rollouts(pose0, obs0, excl, world, steps, np.full(Q, self.radius), self.Nsims,
+                                          self.seed * 1000003 + self.calls)
+        for q, (w, t, n, _) in enumerate(sel):
+            r = rew[q]
+            b = int(np.argmax(r))  # `if rew > best_reward` keeps the first maximum
+            tail = [int(a) if a != 255 else -1 for a in acts[q, b, :steps[q]]]  # -1: infeasible draw -> (0, 0) action
+            t.backprop(n, float(r.mean()), float(r[b]), n.actions + tail, obs[q, b], self.gamma)
+
+    # -- ig_mcts.find_next_action for every robot of every world ------------------------------------------
+    def plan(self, poses):
+        """poses [N, R, 3] current (x, y, heading) of the IG agents.  Returns (actions [N, R, 2] = (v, omega) of
+        the first step of each robot's best path, best-path primitive sequences)."""
+        poses = np.asarray(poses, dtype=np.float64).reshape(self.N, self.R, 3)
+        trees = [[_Tree(poses[w, r], self.horizon, self.c_p, self.comm_n) for w in range(self.N)] for r in range(self.R)]
+        for r in range(self.R):  # Tree.__init__ expands the root
+            self._expand([(w, t, t.root) for w, t in enumerate(trees[r])])
+        published = [[None] * self.N for _ in range(self.R)]
+        for cycle in range(self.Ncycles):
+            for r in range(self.R):  # robots in index order; a robot sees what the earlier ones just published
+                for w in range(self.N):
+                    for other in range(self.R):
+                        if other != r and published[other][w] is not None:
+                            trees[r][w].comms[other] = published[other][w]
+                for _ in range(self.Ntree):
+                    self._grow_all(r, trees[r])
+                for w in range(self.N):
+                    published[r][w] = [(d[0], d[1], d[2]) for d in trees[r][w].dist]
+        self.trees = trees
+        actions = np.zeros((self.N, self.R, 2))
+        paths = [[None] * self.R for _ in range(self.N)]
+        for r in range(self.R):
+            for w in range(self.N):
+                seq = trees[r][w].dist[0][0]  # best_paths.X[0].action_seq
+                paths[w][r] = list(seq)
+                if seq and seq[0] >= 0:
+                    actions[w, r] = PRIMITIVES[seq[0]]
+        return actions, paths

@@ -30,7 +30,7 @@ class InfoGain(object):
         L.cagym_ig_update_belief.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_double, C.c_double, vp, vp]
         L.cagym_ig_mi_reward.argtypes = [vp, vp, vp, C.c_int, vp, vp]
         L.cagym_ig_next_pose.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_double, vp, vp, vp]
-        L.cagym_ig_rollouts.argtypes = [vp] * 7 + [C.c_int] * 4 + [C.c_double] * 3 + [C.c_uint64, vp, vp, vp, vp]
+        L.cagym_ig_rollouts.argtypes = [vp] * 7 + [C.c_int] * 4 + [C.c_double] * 3 + [C.c_uint64, vp, vp, vp, vp, vp]
         with torch.cuda.device(benv.device):
             _lib.check(L, benv.h, L.cagym_ig_init(benv.h, benv._stream()), "cagym_ig_init")
         d2, bel = vp(), vp()
@@ -108,8 +108,10 @@ class InfoGain(object):
         _lib.check(self.L, self.b.h, rc, "cagym_ig_next_pose")
         return nxt, ok
 
-    def rollouts(self, pose0, observed0, exclude, world, n_steps, radius, nsims, seed, max_steps=None):
-        """nsims random roll-outs per query; returns (rewards [Q,nsims], actions [Q,nsims,H], final_pose)."""
+    def rollouts(self, pose0, observed0, exclude, world, n_steps, radius, nsims, seed, max_steps=None,
+                 want_observed=False):
+        """nsims random roll-outs per query; returns (rewards [Q,nsims], actions [Q,nsims,H], final_pose) and, with
+        want_observed, the cells observed along each roll-out [Q,nsims,60]."""
         pose0 = self._t(pose0, torch.float64, (-1, 3))
         Q = pose0.shape[0]
         observed0 = self._t(observed0, torch.int64, (Q, 60))
@@ -121,13 +123,15 @@ class InfoGain(object):
         rew = torch.empty((Q, nsims), dtype=torch.float64, device=self.b.device)
         acts = torch.full((Q, nsims, max(H, 1)), 255, dtype=torch.uint8, device=self.b.device)
         fin = torch.empty((Q, nsims, 3), dtype=torch.float64, device=self.b.device)
+        obs_out = torch.empty((Q, nsims, 60), dtype=torch.int64, device=self.b.device) if want_observed else None
         with torch.cuda.device(self.b.device):
             rc = self.L.cagym_ig_rollouts(self.b.h, pose0.data_ptr(), observed0.data_ptr(), exclude.data_ptr(),
                                           world.data_ptr(), n_steps.data_ptr(), radius.data_ptr(), Q, int(nsims),
                                           max(H, 1), self.xdt, self.dt, self.fov, self.range, int(seed),
-                                          rew.data_ptr(), acts.data_ptr(), fin.data_ptr(), self.b._stream())
+                                          rew.data_ptr(), acts.data_ptr(), fin.data_ptr(),
+                                          None if obs_out is None else obs_out.data_ptr(), self.b._stream())
         _lib.check(self.L, self.b.h, rc, "cagym_ig_rollouts")
-        return rew, acts, fin
+        return (rew, acts, fin, obs_out) if want_observed else (rew, acts, fin)
 
 
 def find_targets_in_obs(other_agents_states, detect_range=5.0):
@@ -137,3 +141,29 @@ def find_targets_in_obs(other_agents_states, detect_range=5.0):
     oas = other_agents_states
     r = torch.sqrt(oas[..., 0] ** 2 + oas[..., 1] ** 2)
     return (oas[..., 9] == 1.0) & (r <= detect_range), oas[..., 0:2]
+
+
+class InfoGainBackend(object):
+    """numpy-in / numpy-out adapter of InfoGain for dmcts.DecMCTSPlanner (host tree, device primitives)."""
+
+    def __init__(self, ig):
+        self.ig = ig
+
+    def next_pose(self, poses, prim_idx, world, radius):
+        acts = PRIMITIVES[np.asarray(prim_idx)]
+        nxt, ok = self.ig.next_pose(poses, acts, world, radius)
+        torch.cuda.synchronize(self.ig.b.device)
+        return nxt.cpu().numpy(), ok.cpu().numpy().astype(bool)
+
+    def visible_cells(self, poses, world):
+        if len(poses) == 0:
+            return np.zeros((0, 60), dtype=np.uint64)
+        m = self.ig.visible_cells(poses, world)
+        return m.cpu().numpy().view(np.uint64)
+
+    def rollouts(self, pose0, observed0, exclude, world, n_steps, radius, nsims, seed):
+        H = int(max(1, np.max(n_steps)))
+        rew, acts, fin, obs = self.ig.rollouts(pose0, np.ascontiguousarray(observed0).view(np.int64),
+                                               np.ascontiguousarray(exclude).view(np.int64), world, n_steps, radius,
+                                               nsims, seed, max_steps=H, want_observed=True)
+        return rew.cpu().numpy(), acts.cpu().numpy(), obs.cpu().numpy().view(np.uint64)

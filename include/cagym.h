@@ -194,11 +194,12 @@ int cagym_ig_next_pose(void* env, const double* poses, const double* actions, co
  * motion primitives (ig_mcts.mcts_avail_actions :247-253; counter-based RNG on (seed, q, sim, step)) from
  * pose0[q] with already-observed set observed0[q]; reward = MI(observed minus exclude[q]) (mcts_reward :234-241).
  * rewards [Q,nsims]; actions [Q,nsims,max_steps] primitive index 0..8 or 255 (infeasible draw; may be NULL);
- * final_pose [Q,nsims,3] (may be NULL). */
+ * final_pose [Q,nsims,3] (may be NULL); observed_out [Q,nsims,60] = cells observed along each roll-out including
+ * observed0, before exclusion (may be NULL) -- the set a robot communicates to its team (MCTS_state.obsvd_cells). */
 int cagym_ig_rollouts(void* env, const double* pose0, const uint64_t* observed0, const uint64_t* exclude,
                       const int32_t* world, const int32_t* n_steps, const double* radius, int Q, int nsims,
                       int max_steps, int xdt, double dt, double fov_rad, double range, uint64_t seed,
-                      double* rewards, uint8_t* actions, double* final_pose, void* stream);
+                      double* rewards, uint8_t* actions, double* final_pose, uint64_t* observed_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -99,7 +99,8 @@ uint32_t cao_ig_rand_primitive(uint64_t seed, uint32_t q, uint32_t sim, uint32_t
 /* Tree._simulate random roll-out (pydecmcts/DecMCTS.py:233-271) + mcts_reward (ig_mcts.py:234-241) */
 double cao_ig_rollout(const double* belief, const double* edf, const double* pose0, const uint64_t* observed0,
                       const uint64_t* exclude, int n_steps, int xdt, double dt, double radius, double fov_rad,
-                      double range, uint64_t seed, uint32_t q, uint32_t sim, uint8_t* actions_out, double* pose_out);
+                      double range, uint64_t seed, uint32_t q, uint32_t sim, uint8_t* actions_out, double* pose_out,
+                      uint64_t* observed_out);
 
 #ifdef __cplusplus
 }

@@ -69,7 +69,7 @@ def lib():
         L.cao_ig_rollout.restype = C.c_double
         L.cao_ig_rollout.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
                                                         C.c_double, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p,
-                                                        C.c_void_p]
+                                                        C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -212,12 +212,15 @@ def next_pose(edf, pose, action, xdt=5, dt=0.1, radius=0.5):
 
 
 def rollout(belief, edf, pose0, observed0, exclude, n_steps, seed, q, sim, xdt=5, dt=0.1, radius=0.5, fov=FOV60,
-            rng=5.0):
+            rng=5.0, want_observed=False):
     pose0 = np.ascontiguousarray(pose0, dtype=np.float64)
     observed0 = np.ascontiguousarray(observed0, dtype=np.uint64)
     exclude = np.ascontiguousarray(exclude, dtype=np.uint64)
-    acts = np.zeros(n_steps, dtype=np.uint8)
+    acts = np.zeros(max(n_steps, 1), dtype=np.uint8)
     pose = np.zeros(3)
+    obs = np.zeros(60, dtype=np.uint64)
     r = lib().cao_ig_rollout(_p(belief), _p(edf), _p(pose0), _p(observed0), _p(exclude), n_steps, xdt, dt, radius,
-                             fov, rng, seed, q, sim, _p(acts), _p(pose))
-    return r, acts, pose
+                             fov, rng, seed, q, sim, _p(acts), _p(pose), _p(obs))
+    if want_observed:
+        return r, acts[:n_steps], pose, obs
+    return r, acts[:n_steps], pose

@@ -477,7 +477,7 @@ def ga3c_states():
     print("%-28s          %8.1f KB" % ("ga3c_states", os.path.getsize(path) / 1024))
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--dmcts-only" not in sys.argv:
     if "--ga3c-only" in sys.argv:
         ga3c_states()
         sys.exit(0)
@@ -486,3 +486,46 @@ if __name__ == "__main__":
     ig_primitives()
     if "--ig-only" not in sys.argv:
         ga3c_states()
+        dmcts_reference()
+
+
+def dmcts_reference(n_seeds=6, n_steps=6):
+    """Cumulative team reward of the reference's own Dec-MCTS loop (experiments/src/dmcts.py:50-95) on its
+    default scenario IG_agent_crossing with a tiny planning budget, for a few np.random seeds.  The planner uses
+    the global np.random stream, so this pins only the statistics (range) the planner must reproduce."""
+    from gym_collision_avoidance.envs.collision_avoidance_env import CollisionAvoidanceEnv
+    Config.EVALUATE_MODE = True
+    Config.HOMOGENEOUS_TESTING = False
+    Config.TRAIN_SINGLE_AGENT = False
+    set_max_agents(10)
+    Config.STATES_IN_OBS = ['radius', 'heading_global_frame', 'pos_global_frame', 'pref_speed', 'other_agents_states']
+    out = {"cum_reward": [], "first_actions": [], "pos": []}
+    for seed in range(n_seeds):
+        np.random.seed(seed)
+        with rh.quiet():
+            env = CollisionAvoidanceEnv()
+            env.reset()
+            for i in range(3):
+                env.agents[i].policy.set_param(ego_agent=env.agents[i], occ_map=env.map, map_size=(30, 30),
+                                               detect_fov=60.0, map_res=0.1, detect_range=5.0, Ntree=5, Nsims=3,
+                                               parallelize_sims=False, mcts_cp=1., mcts_horizon=4,
+                                               parallelize_agents=False, dt=0.1, xdt=5, mcts_gamma=0.95, Ncycles=2)
+        cum, acts, pos = [0.0], [], []
+        for t in range(n_steps):
+            with rh.quiet():
+                env.step({})
+            cum.append(cum[-1] + env.agents[0].policy.team_reward)
+            acts.append([np.asarray(a.past_actions[0]) for a in env.agents[:3]])
+            pos.append([np.append(a.pos_global_frame, a.heading_global_frame) for a in env.agents[:3]])
+        out["cum_reward"].append(cum)
+        out["first_actions"].append(acts)
+        out["pos"].append(pos)
+    Config.STATES_IN_OBS = list(OBS_KEYS)
+    path = os.path.join(HERE, "ig_dmcts_reference.npz")
+    np.savez_compressed(path, **{k: np.array(v, dtype=np.float64) for k, v in out.items()})
+    print("%-28s          %8.1f KB" % ("ig_dmcts_reference", os.path.getsize(path) / 1024))
+    print(np.array(out["cum_reward"])[:, -1])
+
+
+if "--dmcts-only" in sys.argv:
+    dmcts_reference()
