@@ -164,6 +164,33 @@ __device__ __forceinline__ PairIdx pair_of(int p, int M, uint32_t inv_m) {
     return q;
 }
 
+// Unordered pairs of M slots by circular difference: (i, i+k mod M) for k = 1..(M-1)/2, plus the M/2 diameters
+// when M is even.  p -> (world of the workgroup, i, j) with compile-time divisors only.
+struct UPair {
+    int wl, i, j;
+};
+template <int MT>
+struct UnorderedPairs {
+    static constexpr int N = MT > 0 ? MT * (MT - 1) / 2 : 1;
+    static constexpr int H = MT > 0 ? (MT - 1) / 2 : 1;
+    static constexpr int MM = MT > 0 ? MT : 1;
+    __device__ static __forceinline__ UPair of(int p) {
+        UPair q;
+        q.wl = p / N;
+        const int u = p - q.wl * N;
+        if (u < MM * H) {
+            const int k = u / MM;
+            q.i = u - k * MM;
+            q.j = q.i + k + 1;
+            if (q.j >= MM) q.j -= MM;
+        } else {
+            q.i = u - MM * H;
+            q.j = q.i + MM / 2;
+        }
+        return q;
+    }
+};
+
 // One env.step() of the workgroup's worlds.  Agent registers A live on wave 0 (tid < 64) only; the pair
 // phases keep nothing in registers across barriers (everything is re-read from LDS).
 template <int NT, int MT, int WPWT, bool AUTO_RESET>
@@ -185,6 +212,42 @@ __device__ inline void step_core2(const CagymDev& D, const Lds2& W, LaneCtx& C, 
     STAMP(0);
     // ---- P1: ORCA half-planes, one lane per (ego, neighbour) -------------------------------------------
     if (any_rvo) {
+        if (MT > 0) {
+            // compile-time M: one lane per UNORDERED pair writes both half-planes (orca_pair is exactly odd
+            // under ego <-> other), halving the lanes and rounds of this phase
+            if (agent_lane) {
+                W.dsq[tid * MP + C.slot] = INFINITY;
+                for (int l = M; l < MP; l++) W.dsq[tid * MP + l] = INFINITY;
+            }
+            const int nup = C.wpw * UnorderedPairs<MT>::N;
+            for (int p = tid; p < nup; p += NT) {
+                const UPair q = UnorderedPairs<MT>::of(p);
+                const int n = W.wn[q.wl];
+                const int a = q.wl * M + q.i, b = q.wl * M + q.j;
+                const uint32_t sa = W.tst[a], sb = W.tst[b];
+                const bool both = q.i < n && q.j < n;
+                const bool on_a = both && ST_POLICY(sa) == CAGYM_POL_RVO && !(sa & CAGYM_FLAG_DONE);
+                const bool on_b = both && ST_POLICY(sb) == CAGYM_POL_RVO && !(sb & CAGYM_FLAG_DONE);
+                float dq = INFINITY;
+                if (on_a || on_b) {
+                    const float vax = (float)W.tvx[a], vay = (float)W.tvy[a];
+                    const OrcaPair g = orca_pair((float)W.tpx[a], (float)W.tpy[a], vax, vay,
+                                                 (float)((1 + 15e-2) * W.tr[a]), (float)D.dt, W.tpx[b], W.tpy[b],
+                                                 W.tvx[b], W.tvy[b], W.tr[b]);
+                    dq = g.d2;
+                    if (on_a) {
+                        const float c = W.tcoop[a];
+                        W.lines[a * MP + q.j] = make_float4(vax + c * g.ux, vay + c * g.uy, g.zx, g.zy);
+                    }
+                    if (on_b) {
+                        const float c = W.tcoop[b];
+                        W.lines[b * MP + q.i] = make_float4((float)W.tvx[b] - c * g.ux, (float)W.tvy[b] - c * g.uy, -g.zx, -g.zy);
+                    }
+                }
+                W.dsq[a * MP + q.j] = on_a ? dq : INFINITY;
+                W.dsq[b * MP + q.i] = on_b ? dq : INFINITY;
+            }
+        } else
         for (int p = tid; p < npairs; p += NT) {
             const PairIdx q = pair_of(p, M, inv_m);
             const int n = W.wn[q.wl];
@@ -300,6 +363,45 @@ __device__ inline void step_core2(const CagymDev& D, const Lds2& W, LaneCtx& C, 
     __syncthreads();  // post-move tile visible; LP scratch (union, pre-move view) is dead
     STAMP(3);
     // ---- P2: pair distances, collision tests (env.py:630-655), OAS sort keys ------------------------------
+    if (MT > 0) {
+        // one lane per unordered pair: the distance (fp64 sqrt) is shared by both directions
+        if (agent_lane) {
+            W.hit[tid * MP + C.slot] = 0;
+            W.gap[tid * MP + C.slot] = INFINITY;
+            W.keys[tid * MP + C.slot] = -INFINITY;
+            for (int l = M; l < MP; l++) {
+                W.hit[tid * MP + l] = 0;
+                W.gap[tid * MP + l] = INFINITY;
+                W.keys[tid * MP + l] = -INFINITY;
+            }
+        }
+        const int nup = C.wpw * UnorderedPairs<MT>::N;
+        for (int p = tid; p < nup; p += NT) {
+            const UPair q = UnorderedPairs<MT>::of(p);
+            const int n = W.wn[q.wl];
+            const int lo = q.wl * M + (q.i < q.j ? q.i : q.j), hi = q.wl * M + (q.i < q.j ? q.j : q.i);
+            const int slo = lo - q.wl * M, shi = hi - q.wl * M;
+            double klo = -INFINITY, khi = -INFINITY, gp = INFINITY;
+            uint8_t ht = 0;
+            if (shi < n) {  // slo < shi < n
+                const double dx = W.tpx[hi] - W.tpx[lo], dy = W.tpy[hi] - W.tpy[lo];
+                const double d = norm2(dx, dy);
+                const double rl = W.tr[lo], rh = W.tr[hi];
+                const bool skip = ST_POLICY(W.tst[hi]) == CAGYM_POL_STATIC && !D.collide_static;  // env.py:643 (Q8)
+                const double cr = rl + rh;
+                ht = (!skip && d <= cr) ? 1 : 0;
+                if (!skip) gp = d - cr;  // lower index only (Q7)
+                klo = d - rl - rh;
+                khi = d - rh - rl;
+            }
+            W.hit[lo * MP + shi] = ht;
+            W.hit[hi * MP + slo] = ht;
+            W.gap[lo * MP + shi] = gp;
+            W.gap[hi * MP + slo] = INFINITY;
+            W.keys[lo * MP + shi] = klo;
+            W.keys[hi * MP + slo] = khi;
+        }
+    } else
     for (int p = tid; p < npairs; p += NT) {
         const PairIdx q = pair_of(p, M, inv_m);
         const int n = W.wn[q.wl];

@@ -140,9 +140,15 @@ __device__ __forceinline__ OrcaEgo orca_ego(const Agent& A, double dt) {
     return E;
 }
 
-// One ORCA half-plane ego <- other (Agent::computeNewVelocity body), other given in fp64 as stored.
-__device__ __forceinline__ float4 orca_line(float pex, float pey, float vex, float vey, float re, float c,
-                                            float time_step, double opx, double opy, double ovx, double ovy, double orad) {
+// Geometry of one ORCA half-plane ego <- other (Agent::computeNewVelocity body): u (the smallest change of
+// the relative velocity that leaves the velocity obstacle), the line direction and the squared centre distance.
+// Every operation is odd or even under (ego <-> other), and IEEE rounding is sign-symmetric, so the half-plane
+// of the reversed pair is exactly (-u, -direction): one evaluation serves both agents of a pair (P1 below).
+struct OrcaPair {
+    float ux, uy, zx, zy, d2;
+};
+__device__ __forceinline__ OrcaPair orca_pair(float pex, float pey, float vex, float vey, float re, float time_step,
+                                              double opx, double opy, double ovx, double ovy, double orad) {
     const float inv_th = 1.0f / 5.0f;
     float ox = (float)opx, oy = (float)opy;
     float rpx = ox - pex, rpy = oy - pey;
@@ -150,8 +156,8 @@ __device__ __forceinline__ float4 orca_line(float pex, float pey, float vex, flo
     float ro = (float)((1 + 15e-2) * orad);
     float d2 = rpx * rpx + rpy * rpy;
     float cr = re + ro, crsq = cr * cr;
-    float ux, uy;
-    float4 ln;
+    OrcaPair g;
+    g.d2 = d2;
     if (d2 > crsq) {
         float wx = rvx - inv_th * rpx, wy = rvy - inv_th * rpy;
         float wlsq = wx * wx + wy * wy;
@@ -160,24 +166,24 @@ __device__ __forceinline__ float4 orca_line(float pex, float pey, float vex, flo
             float wl = sqrtf(wlsq);
             float inv = 1.0f / wl;
             float uwx = wx * inv, uwy = wy * inv;
-            ln.z = uwy;
-            ln.w = -uwx;
+            g.zx = uwy;
+            g.zy = -uwx;
             float s = cr * inv_th - wl;
-            ux = s * uwx;
-            uy = s * uwy;
+            g.ux = s * uwx;
+            g.uy = s * uwy;
         } else {
             float leg = sqrtf(d2 - crsq);
             float inv = 1.0f / d2;
             if (detf(rpx, rpy, wx, wy) > 0.0f) {
-                ln.z = (rpx * leg - rpy * cr) * inv;
-                ln.w = (rpx * cr + rpy * leg) * inv;
+                g.zx = (rpx * leg - rpy * cr) * inv;
+                g.zy = (rpx * cr + rpy * leg) * inv;
             } else {
-                ln.z = -((rpx * leg + rpy * cr) * inv);
-                ln.w = -((-rpx * cr + rpy * leg) * inv);
+                g.zx = -((rpx * leg + rpy * cr) * inv);
+                g.zy = -((-rpx * cr + rpy * leg) * inv);
             }
-            float dp2 = rvx * ln.z + rvy * ln.w;
-            ux = dp2 * ln.z - rvx;
-            uy = dp2 * ln.w - rvy;
+            float dp2 = rvx * g.zx + rvy * g.zy;
+            g.ux = dp2 * g.zx - rvx;
+            g.uy = dp2 * g.zy - rvy;
         }
     } else {
         float inv_ts = 1.0f / time_step;
@@ -185,15 +191,20 @@ __device__ __forceinline__ float4 orca_line(float pex, float pey, float vex, flo
         float wl = sqrtf(wx * wx + wy * wy);
         float inv = 1.0f / wl;
         float uwx = wx * inv, uwy = wy * inv;
-        ln.z = uwy;
-        ln.w = -uwx;
+        g.zx = uwy;
+        g.zy = -uwx;
         float s = cr * inv_ts - wl;
-        ux = s * uwx;
-        uy = s * uwy;
+        g.ux = s * uwx;
+        g.uy = s * uwy;
     }
-    ln.x = vex + c * ux;
-    ln.y = vey + c * uy;
-    return ln;
+    return g;
+}
+
+// One ORCA half-plane ego <- other; c = the ego's share of the avoidance (collaboration coefficient).
+__device__ __forceinline__ float4 orca_line(float pex, float pey, float vex, float vey, float re, float c,
+                                            float time_step, double opx, double opy, double ovx, double ovy, double orad) {
+    const OrcaPair g = orca_pair(pex, pey, vex, vey, re, time_step, opx, opy, ovx, ovy, orad);
+    return make_float4(vex + c * g.ux, vey + c * g.uy, g.zx, g.zy);
 }
 
 // Agent::update (fp32) and the fp64 tail of RVOPolicy.find_next_action (RVOPolicy.py:91-106).
