@@ -191,6 +191,13 @@ struct UnorderedPairs {
     }
 };
 
+// Compact list of the agent lanes that solve an ORCA LP in the next step (wave 0, inside `if (agent_lane)`).
+__device__ __forceinline__ void publish_rvo_list(const Lds2& W, int tid, bool is_rvo) {
+    const unsigned long long m = __ballot(is_rvo);
+    if (is_rvo) W.lpk[__popcll(m & ((1ull << tid) - 1ull))] = tid;
+    if (tid == 0) W.lpmask[0] = (unsigned long long)__popcll(m);
+}
+
 // One env.step() of the workgroup's worlds.  Agent registers A live on wave 0 (tid < 64) only; the pair
 // phases keep nothing in registers across barriers (everything is re-read from LDS).
 template <int NT, int MT, int WPWT, bool AUTO_RESET>
@@ -288,49 +295,31 @@ __device__ inline void step_core2(const CagymDev& D, const Lds2& W, LaneCtx& C, 
         __syncthreads();
         STAMP(2);
     }
-    // ---- S1: _take_action (env.py:287-340).  RVO: linearProgram2 per agent lane, then the (rare, long)
-    //      linearProgram3 of the infeasible agents cooperatively on 16-lane groups of every wave ------------
+    // ---- S1: _take_action (env.py:287-340).  RVO: linearProgram2 (+ linearProgram3 when infeasible) of every
+    //      live RVO agent on a GW-lane group, lane j <-> half-plane j; the agents come from the compact list the
+    //      previous S2 (or the kernel prologue) published ----------------------------------------------------
     if (any_rvo) {
-        if (agent_lane) {
-            const uint32_t st0 = W.tst[tid];
-            const bool is_rvo = C.valid && C.active && !(st0 & CAGYM_FLAG_DONE) && ST_POLICY(st0) == CAGYM_POL_RVO;
-            bool need3 = false;
-            if (is_rvo) {
-                const Agent A = lds_load_agent(W, tid);
-                const OrcaEgo E = orca_ego(A, D.dt);
-                const int nn = (C.n - 1) < CAGYM_MAXNB ? (C.n - 1) : CAGYM_MAXNB;
-                float nvx, nvy;
-                const int fail = orca_lp2_unrolled(W.sorted, tid, nn, E.max_speed, E.pvx, E.pvy, nvx, nvy, AS);
-                W.lpv[tid] = make_float2(nvx, nvy);
-                W.lpk[tid] = fail;
-                W.lpr[tid] = E.max_speed;
-                need3 = fail < nn;
+        constexpr int GW = MT > 0 && MT <= 5 ? 4 : (MT > 0 && MT <= 10 ? 8 : 16), NG = NT / GW;
+        const int cnt = (int)W.lpmask[0];
+        const int g = tid / GW, j = tid & (GW - 1);
+        for (int base = 0; base < cnt; base += NG) {
+            const int idx = base + g;
+            if (idx < cnt) {
+                const int a = W.lpk[idx];
+                const int wl = (int)__umulhi((uint32_t)a, inv_m);
+                const int n = W.wn[wl];
+                const int nn = (n - 1) < CAGYM_MAXNB ? (n - 1) : CAGYM_MAXNB;
+                // prefVelocity and maxSpeed of the ego (RVOPolicy.py:65-85), as orca_ego
+                const double gx = W.tgx[a] - W.tpx[a], gy = W.tgy[a] - W.tpy[a];
+                const double pref = W.tpref[a];
+                const double sc = pref / norm2(gx, gy);
+                float vx, vy;
+                orca_lp_group<GW>(W.sorted, W.proj, a, j, nn, (float)pref, (float)(sc * gx), (float)(sc * gy), vx, vy, AS);
+                if (j == 0) W.lpv[a] = make_float2(vx, vy);
             }
-            const unsigned long long m = __ballot(need3);
-            if (tid == 0) W.lpmask[0] = m;
         }
         __syncthreads();
         STAMP(8);
-        const unsigned long long fm = W.lpmask[0];
-        if (fm) {
-            const int cnt = __popcll(fm), g = tid >> 4, j = tid & 15;
-            for (int base = 0; base < cnt; base += NT / 16) {
-                int idx = base + g;
-                if (idx < cnt) {
-                    unsigned long long mm = fm;
-                    for (int s = 0; s < idx; s++) mm &= mm - 1ull;
-                    const int a = __ffsll((long long)mm) - 1;
-                    const int wl = (int)__umulhi((uint32_t)a, inv_m);
-                    const int n = W.wn[wl];
-                    const int nn = (n - 1) < CAGYM_MAXNB ? (n - 1) : CAGYM_MAXNB;
-                    float2 v = W.lpv[a];
-                    orca_lp3_group(W.sorted, W.proj, a, j, nn, W.lpk[a], W.lpr[a], v.x, v.y, AS);
-                    if (j == 0) W.lpv[a] = v;
-                }
-            }
-            __syncthreads();
-        }
-        STAMP(9);
     }
     if (agent_lane && C.valid && C.active) {
         Agent A = lds_load_agent(W, tid);
@@ -514,6 +503,8 @@ __device__ inline void step_core2(const CagymDev& D, const Lds2& W, LaneCtx& C, 
         }
         W.tst[tid] = A.st;
         if (tid == 0) W.flag[0] = any_reset ? 1 : 0;
+        if (any_rvo)
+            publish_rvo_list(W, tid, C.valid && C.active && !(A.st & CAGYM_FLAG_DONE) && ST_POLICY(A.st) == CAGYM_POL_RVO);
     }
     __syncthreads();
     STAMP(5);
@@ -620,6 +611,7 @@ __global__ void __launch_bounds__(NT, (NT <= 256 ? 3 : 2)) k_rollout2(CagymDev D
         }
         lds_store_agent(W, A, threadIdx.x);
         if (C.wl < C.wpw && C.slot == 0) W.wn[C.wl] = C.valid ? C.n : 0;
+        publish_rvo_list(W, threadIdx.x, C.valid && C.active && !(A.st & CAGYM_FLAG_DONE) && ST_POLICY(A.st) == CAGYM_POL_RVO);
     }
     const size_t NM = (size_t)D.N * M;
 #pragma nounroll
@@ -664,6 +656,7 @@ __global__ void __launch_bounds__(NT) k_step2(CagymDev D, const float* ext, Cagy
         }
         lds_store_agent(W, A, threadIdx.x);
         if (C.wl < C.wpw && C.slot == 0) W.wn[C.wl] = C.valid ? C.n : 0;
+        publish_rvo_list(W, threadIdx.x, C.valid && C.active && !(A.st & CAGYM_FLAG_DONE) && ST_POLICY(A.st) == CAGYM_POL_RVO);
     }
     step_core2<NT, MT, WPWT, AUTO_RESET>(D, W, C, ext, out, ep_ret, ep_len, any_rvo != 0);
     if (C.valid) {

@@ -413,3 +413,147 @@ __device__ inline void orca_lp3_group(const float4* L, float4* P, int a, int j, 
         distance = detf(li.z, li.w, li.x - rx, li.y - ry);
     }
 }
+
+// ---- linearProgram2 + linearProgram3 of one ego on a GW-lane group (GW = 4, 8 or 16) ---------------------------
+// Lane j of the group holds half-plane j.  Line i only ever meets lines j < i, so GW lanes serve nn <= GW + 1
+// half-planes.  linearProgram1's interval clipping is a min/max/any reduction over the lanes j < i (same
+// argument as orca_lp3_group above); the reductions are DPP row operations (no LDS round trip).  All lanes of
+// a group run the same control flow; the groups of one wave may diverge from each other.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    const int x = __builtin_bit_cast(int, v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(x, x, CTRL, 0xf, 0xf, false));
+}
+#define CAGYM_DPP_QUAD_XOR1 0xB1   // quad_perm [1,0,3,2]
+#define CAGYM_DPP_QUAD_XOR2 0x4E   // quad_perm [2,3,0,1]
+#define CAGYM_DPP_ROW_MIRROR 0x140
+#define CAGYM_DPP_ROW_HALF_MIRROR 0x141
+template <int GW>
+__device__ __forceinline__ float grp_max(float v) {
+    if (GW >= 16) v = fmaxf(v, dpp_f32<CAGYM_DPP_ROW_MIRROR>(v));
+    if (GW >= 8) v = fmaxf(v, dpp_f32<CAGYM_DPP_ROW_HALF_MIRROR>(v));
+    v = fmaxf(v, dpp_f32<CAGYM_DPP_QUAD_XOR2>(v));
+    return fmaxf(v, dpp_f32<CAGYM_DPP_QUAD_XOR1>(v));
+}
+template <int GW>
+__device__ __forceinline__ float grp_min(float v) {
+    if (GW >= 16) v = fminf(v, dpp_f32<CAGYM_DPP_ROW_MIRROR>(v));
+    if (GW >= 8) v = fminf(v, dpp_f32<CAGYM_DPP_ROW_HALF_MIRROR>(v));
+    v = fminf(v, dpp_f32<CAGYM_DPP_QUAD_XOR2>(v));
+    return fminf(v, dpp_f32<CAGYM_DPP_QUAD_XOR1>(v));
+}
+
+// linearProgram1 on the group: half-plane `ln` against the lanes' own lines (`mine`, taking part when `take`).
+// dir_opt as in RVO2.  Returns false when infeasible (result untouched).
+template <int GW>
+__device__ __forceinline__ bool orca_lp1_group(const float4 ln, const float4 mine, bool take, float radius, float ox,
+                                               float oy, bool dir_opt, int gbase, float& rx, float& ry) {
+    const float dot = ln.x * ln.z + ln.y * ln.w;
+    const float disc = dot * dot + radius * radius - (ln.x * ln.x + ln.y * ln.y);
+    if (disc < 0.0f) return false;
+    const float sq = sqrtf(disc);
+    float tl = -dot - sq, tr = -dot + sq;
+    float ltl = -INFINITY, ltr = INFINITY;
+    bool lfail = false;
+    if (take) {
+        const float den = detf(ln.z, ln.w, mine.z, mine.w);
+        const float num = detf(mine.z, mine.w, ln.x - mine.x, ln.y - mine.y);
+        if (fabsf(den) <= RVO_EPS) {
+            lfail = num < 0.0f;
+        } else {
+            const float t = num / den;
+            if (den >= 0.0f) ltr = t;
+            else ltl = t;
+        }
+    }
+    tl = fmaxf(tl, grp_max<GW>(ltl));
+    tr = fminf(tr, grp_min<GW>(ltr));
+    const bool anyfail = ((__ballot(lfail) >> gbase) & ((1ull << GW) - 1ull)) != 0ull;
+    if (anyfail || tl > tr) return false;
+    float t;
+    if (dir_opt) {
+        t = (ox * ln.z + oy * ln.w > 0.0f) ? tr : tl;
+    } else {
+        t = ln.z * (ox - ln.x) + ln.w * (oy - ln.y);
+        if (t < tl) t = tl;
+        else if (t > tr) t = tr;
+    }
+    rx = ln.x + t * ln.z;
+    ry = ln.y + t * ln.w;
+    return true;
+}
+
+// Agent::computeNewVelocity after the half-planes exist: linearProgram2 on the nn sorted lines of agent column `a`
+// with optimisation velocity (ox, oy), then linearProgram3 from the failing line when infeasible.
+template <int GW>
+__device__ inline void orca_lp_group(const float4* L, float4* P, int a, int j, int nn, float radius, float ox, float oy,
+                                     float& rx, float& ry, int stride) {
+    const int gbase = (threadIdx.x & 63) & ~(GW - 1);
+    const float4 lj = j < nn ? L[j * stride + a] : make_float4(0.f, 0.f, 0.f, 0.f);
+    // every half-plane of the ego in registers up front: one LDS latency instead of one per visited line
+    float4 ln[CAGYM_MAXNB];
+#pragma unroll
+    for (int i = 0; i < CAGYM_MAXNB; i++) ln[i] = L[i * stride + a];  // slots >= nn: stale but in bounds, unused
+    if (ox * ox + oy * oy > radius * radius) {
+        const float inv = 1.0f / sqrtf(ox * ox + oy * oy);
+        rx = ox * inv * radius;
+        ry = oy * inv * radius;
+    } else {
+        rx = ox;
+        ry = oy;
+    }
+    int fail = nn;
+#pragma unroll
+    for (int i = 0; i < CAGYM_MAXNB; i++) {
+        if (i >= fail) continue;  // fail == nn until a line is infeasible
+        const float4 li = ln[i];
+        if (!(detf(li.z, li.w, li.x - rx, li.y - ry) > 0.0f)) continue;
+        if (!orca_lp1_group<GW>(li, lj, j < i, radius, ox, oy, false, gbase, rx, ry))
+            fail = i;  // result keeps the value it had before this line (tempResult)
+    }
+    // linearProgram3
+    float distance = 0.0f;
+#pragma nounroll
+    for (int i = fail; i < nn; i++) {  // rare: lines re-read from LDS, loop kept rolled
+        const float4 li = L[i * stride + a];
+        if (!(detf(li.z, li.w, li.x - rx, li.y - ry) > distance)) continue;
+        // projected line of lane j (j < i); `have` = it exists (not "parallel, same direction")
+        bool have = false;
+        float4 pj = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (j < i) {
+            const float d = detf(li.z, li.w, lj.z, lj.w);
+            have = true;
+            if (fabsf(d) <= RVO_EPS) {
+                if (li.z * lj.z + li.w * lj.w > 0.0f) have = false;
+                pj.x = 0.5f * (li.x + lj.x);
+                pj.y = 0.5f * (li.y + lj.y);
+            } else {
+                const float s = detf(lj.z, lj.w, li.x - lj.x, li.y - lj.y) / d;
+                pj.x = li.x + s * li.z;
+                pj.y = li.y + s * li.w;
+            }
+            const float ddx = lj.z - li.z, ddy = lj.w - li.w;
+            const float inv = 1.0f / sqrtf(ddx * ddx + ddy * ddy);
+            pj.z = ddx * inv;
+            pj.w = ddy * inv;
+            if (have) P[j * stride + a] = pj;
+        }
+        const uint32_t hmask = (uint32_t)((__ballot(have) >> gbase) & ((1ull << GW) - 1ull));
+        const float px = -li.w, py = li.z;
+        const float tx = rx, ty = ry;
+        float qx = px * radius, qy = py * radius;  // linearProgram2, directionOpt
+        bool failed = false;
+        for (int k = 0; k < i; k++) {
+            if (!((hmask >> k) & 1u)) continue;
+            const float4 pk = P[k * stride + a];
+            if (!(detf(pk.z, pk.w, pk.x - qx, pk.y - qy) > 0.0f)) continue;
+            if (!orca_lp1_group<GW>(pk, pj, j < k && have, radius, px, py, true, gbase, qx, qy)) {
+                failed = true;
+                break;
+            }
+        }
+        if (failed) { rx = tx; ry = ty; }
+        else { rx = qx; ry = qy; }
+        distance = detf(li.z, li.w, li.x - rx, li.y - ry);
+    }
+}
