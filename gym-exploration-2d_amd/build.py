@@ -41,8 +41,7 @@ def build(force=False, verbose=False):
     objs = []
     for src in SOURCES:
         obj = os.path.join(CSRC, src.replace(".hip", ".o"))
-        extra = ["-DWPW10=" + os.environ["CAGYM_WPW10"]] if os.environ.get("CAGYM_WPW10") else []  # tuning experiments
-        cmd = [hipcc, "--offload-arch=" + ARCH, "-c"] + FLAGS + extra + ["-o", obj, os.path.join(CSRC, src)]
+        cmd = [hipcc, "--offload-arch=" + ARCH, "-c"] + FLAGS + ["-o", obj, os.path.join(CSRC, src)]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)

@@ -30,6 +30,7 @@ struct Env {
     bool ig_ready = false;
     int any_rvo = 1;
     int generation = 2;  // CAGYM_KERNEL=v1 selects the one-lane-per-agent kernels (A/B only)
+    int wpw10 = 5;       // worlds per workgroup of the M = 10 kernels (4 while all workgroups are co-resident)
 };
 
 int fail(Env* e, int code, const std::string& msg) {
@@ -71,24 +72,25 @@ CagymOut to_out(const cagym_outputs* o) {
     return r;
 }
 
-#ifndef WPW10
-#define WPW10 5 /* worlds per workgroup of the M = 10 specialisation: 500 pair slots = 2 rounds of 256 lanes */
-#endif
-
 // worlds per workgroup of the compile-time specialisations (0 = generic: 64 / M worlds, LDS stride 64)
-//   M = 4 : 16 worlds, 256 pair slots = 1 round of 256 lanes
-//   M = 10:  5 worlds, 500 pair slots = 2 rounds of 256 lanes, 4 workgroups per CU
-//   M = 20:  2 worlds, 800 pair slots = 2 rounds of 512 lanes
+//   M = 4 : 16 worlds,  96 unordered pairs per phase round of 256 lanes
+//   M = 10:  5 worlds (225 unordered / 500 directed pair slots, ~35 live agents = 2 rounds of 32 LP groups), or
+//            4 worlds while every workgroup of the launch is co-resident (<= 4 per CU): ~28 live agents = one
+//            round of LP groups; measured 4096 worlds: 259 vs 247 M env-steps/s, 65536 worlds: 342 vs 392
+//   M = 20:  2 worlds, 380 unordered / 800 directed pair slots on 512 lanes
 #define WPW20 2
-inline int wpw_spec(int M) { return M == 10 ? WPW10 : (M == 20 ? WPW20 : 0); }
+inline int wpw_spec(const Env* e) {
+    const int M = e->cfg.max_agents;
+    return M == 10 ? e->wpw10 : (M == 20 ? WPW20 : 0);
+}
 inline int n_wg2(const Env* e) {
     const int M = e->cfg.max_agents;
-    const int wpw = wpw_spec(M) ? wpw_spec(M) : CAGYM_WAVE / M;
+    const int wpw = wpw_spec(e) ? wpw_spec(e) : CAGYM_WAVE / M;
     return (e->cfg.n_worlds + wpw - 1) / wpw;
 }
 inline size_t lds2_bytes(const Env* e) {
     const int M = e->cfg.max_agents;
-    return cagym_lds2_bytes(M, cagym_as(M, wpw_spec(M)));
+    return cagym_lds2_bytes(M, cagym_as(M, wpw_spec(e)));
 }
 
 inline int n_waves(const Env* e) {
@@ -163,21 +165,34 @@ int cagym_create(const cagym_config* cfg, void** env_out) {
     {
         const char* g = getenv("CAGYM_KERNEL");
         if (g && (!strcmp(g, "v1") || !strcmp(g, "1"))) e->generation = 1;
+        {
+            hipDeviceProp_t prop;
+            int cus = 256;
+            if (hipGetDeviceProperties(&prop, e->cfg.device) == hipSuccess && prop.multiProcessorCount > 0)
+                cus = prop.multiProcessorCount;
+            e->wpw10 = (e->cfg.n_worlds + 3) / 4 <= 4 * cus ? 4 : 5;
+            const char* w = getenv("CAGYM_WPW10");  // diagnostics
+            if (w && (w[0] == '4' || w[0] == '5')) e->wpw10 = w[0] - '0';
+        }
         int lds2 = (int)lds2_bytes(e);
         if (lds2 > 160 * 1024) e->generation = 1;
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<256, 0, 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<256, 10, WPW10, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<256, 10, 5, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<256, 10, 4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<256, 4, 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<512, 20, WPW20, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<256, 4, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<256, 4, 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<512, 20, WPW20, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<512, 20, WPW20, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<256, 10, WPW10, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<256, 10, WPW10, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<256, 10, 5, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<256, 10, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<256, 10, 5, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<256, 10, 4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<512, 0, 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<256, 0, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<256, 10, WPW10, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<256, 10, 5, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<256, 10, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<256, 4, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<512, 20, WPW20, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<512, 0, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
@@ -283,7 +298,8 @@ int cagym_step(void* env, const float* ext_actions, const cagym_outputs* out, vo
     const int M = e->cfg.max_agents;
     if (e->generation == 2) {
         const size_t lds2 = lds2_bytes(e);
-        if (M == 10) hipLaunchKernelGGL((k_step2<256, 10, WPW10, false>), dim3(n_wg2(e)), dim3(256), lds2, st, e->D, ext_actions, o, e->any_rvo);
+        if (M == 10 && e->wpw10 == 4) hipLaunchKernelGGL((k_step2<256, 10, 4, false>), dim3(n_wg2(e)), dim3(256), lds2, st, e->D, ext_actions, o, e->any_rvo);
+        else if (M == 10) hipLaunchKernelGGL((k_step2<256, 10, 5, false>), dim3(n_wg2(e)), dim3(256), lds2, st, e->D, ext_actions, o, e->any_rvo);
         else if (M == 4) hipLaunchKernelGGL((k_step2<256, 4, 0, false>), dim3(n_wg2(e)), dim3(256), lds2, st, e->D, ext_actions, o, e->any_rvo);
         else if (M == 20) hipLaunchKernelGGL((k_step2<512, 20, WPW20, false>), dim3(n_wg2(e)), dim3(512), lds2, st, e->D, ext_actions, o, e->any_rvo);
         else if (M <= 12) hipLaunchKernelGGL((k_step2<256, 0, 0, false>), dim3(n_waves(e)), dim3(256), lds2, st, e->D, ext_actions, o, e->any_rvo);
@@ -305,7 +321,8 @@ int cagym_step_autoreset(void* env, const float* ext_actions, const cagym_output
     const int M = e->cfg.max_agents;
     if (e->generation == 2) {
         const size_t lds2 = lds2_bytes(e);
-        if (M == 10) hipLaunchKernelGGL((k_step2<256, 10, WPW10, true>), dim3(n_wg2(e)), dim3(256), lds2, st, e->D, ext_actions, o, e->any_rvo);
+        if (M == 10 && e->wpw10 == 4) hipLaunchKernelGGL((k_step2<256, 10, 4, true>), dim3(n_wg2(e)), dim3(256), lds2, st, e->D, ext_actions, o, e->any_rvo);
+        else if (M == 10) hipLaunchKernelGGL((k_step2<256, 10, 5, true>), dim3(n_wg2(e)), dim3(256), lds2, st, e->D, ext_actions, o, e->any_rvo);
         else if (M == 4) hipLaunchKernelGGL((k_step2<256, 4, 0, true>), dim3(n_wg2(e)), dim3(256), lds2, st, e->D, ext_actions, o, e->any_rvo);
         else if (M == 20) hipLaunchKernelGGL((k_step2<512, 20, WPW20, true>), dim3(n_wg2(e)), dim3(512), lds2, st, e->D, ext_actions, o, e->any_rvo);
         else if (M <= 12) hipLaunchKernelGGL((k_step2<256, 0, 0, true>), dim3(n_waves(e)), dim3(256), lds2, st, e->D, ext_actions, o, e->any_rvo);
@@ -337,7 +354,8 @@ int cagym_rollout(void* env, int n_steps, int auto_reset, const cagym_outputs* o
         if (auto_reset) hipLaunchKernelGGL((k_rollout2<NT, MT, WP, true>), g, dim3(NT), lds2, st, e->D, n_steps, o, e->any_rvo); \
         else hipLaunchKernelGGL((k_rollout2<NT, MT, WP, false>), g, dim3(NT), lds2, st, e->D, n_steps, o, e->any_rvo);         \
     } while (0)
-        if (M == 10) ROLL2(256, 10, WPW10);
+        if (M == 10 && e->wpw10 == 4) ROLL2(256, 10, 4);
+        else if (M == 10) ROLL2(256, 10, 5);
         else if (M == 4) ROLL2(256, 4, 0);
         else if (M == 20) ROLL2(512, 20, WPW20);
         else if (M <= 12) ROLL2(256, 0, 0);

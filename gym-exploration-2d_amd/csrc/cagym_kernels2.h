@@ -32,6 +32,10 @@ __device__ unsigned long long g_stamps[16];
 #define STAMP_BEGIN() do { } while (0)
 #endif
 
+#ifndef CAGYM_GW10
+#define CAGYM_GW10 8  // lanes per ORCA LP group when M <= 10 (nn <= 9 half-planes)
+#endif
+
 struct Lds2 {
     // [64] each: the agent record lives HERE between phases (registers only inside the S phases)
     double *tpx, *tpy, *tvx, *tvy, *tr, *tprx, *tpry;
@@ -299,7 +303,7 @@ __device__ inline void step_core2(const CagymDev& D, const Lds2& W, LaneCtx& C, 
     //      live RVO agent on a GW-lane group, lane j <-> half-plane j; the agents come from the compact list the
     //      previous S2 (or the kernel prologue) published ----------------------------------------------------
     if (any_rvo) {
-        constexpr int GW = MT > 0 && MT <= 5 ? 4 : (MT > 0 && MT <= 10 ? 8 : 16), NG = NT / GW;
+        constexpr int GW = MT > 0 && MT <= 5 ? 4 : (MT > 0 && MT <= 10 ? CAGYM_GW10 : 16), NG = NT / GW;
         const int cnt = (int)W.lpmask[0];
         const int g = tid / GW, j = tid & (GW - 1);
         for (int base = 0; base < cnt; base += NG) {

@@ -179,8 +179,8 @@ def test_full_size_properties():
     assert ep > 0 and int(out[0]) > 10 * int(out[1])
 
 
-@pytest.mark.parametrize("M", [4, 10, 13, 20])
-def test_generation1_and_generation2_kernels_agree_bitwise(M, monkeypatch):
+@pytest.mark.parametrize("M,wpw", [(4, None), (10, "4"), (10, "5"), (13, None), (20, None)])
+def test_generation1_and_generation2_kernels_agree_bitwise(M, wpw, monkeypatch):
     """The phase-split kernels (generation 2, default) share the arithmetic of the one-lane-per-agent
     kernels (generation 1, CAGYM_KERNEL=v1): trajectories, observations and statistics must be identical."""
     import torch
@@ -191,6 +191,8 @@ def test_generation1_and_generation2_kernels_agree_bitwise(M, monkeypatch):
     pol[rng.uniform(size=(3 * N, M)) < 0.05] = scen.POLICY_STATIC
     n_agents = rng.integers(max(1, M - 3), M + 1, 3 * N).astype(np.int32)
     res = []
+    if wpw:
+        monkeypatch.setenv("CAGYM_WPW10", wpw)  # both worlds-per-workgroup variants of the M = 10 kernels
     for gen in ("v1", "v2"):
         monkeypatch.setenv("CAGYM_KERNEL", gen)
         e = _hip(N=N, M=M, game_over_mode=1, n_scenarios=3 * N)
