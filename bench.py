@@ -155,13 +155,18 @@ def main():
         steps_per_launch = args.steps / launches
         launch_ms = dev_ms / launches
         balg = B_ALG[args.policy]
+        # the library's own rule (cagym_api.hip): M = 10 runs 4 worlds per workgroup while the launch is co-resident
+        cus = torch.cuda.get_device_properties(device).multi_processor_count
+        spec = {10: "256, 10, %d" % (4 if (N + 3) // 4 <= 4 * cus else 5), 4: "256, 4, 0", 20: "512, 20, 2"}
+        kernel_name = "%s<%s, true>" % ("k_step2" if args.per_step_launch else "k_rollout2",
+                                        spec.get(M, "256, 0, 0" if M <= 12 else "512, 0, 0"))
         achieved = balg * N * M * steps_per_launch / (launch_ms * 1e-3) / 1e9
         # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate
-        # rocprofv3 --pmc passes; profiles/r1/bench_4096x10_rvo_pmc_hbm.txt): 425.0 B per agent-step, measured on
+        # rocprofv3 --pmc passes; profiles/r1/bench_4096x10_rvo_pmc_hbm.txt): 423.6 B per agent-step, measured on
         # this workload at 64 steps per launch; not re-measured live, so null for any other shape.
         traffic = None
         if (N, M, args.policy, args.per_step_launch) == (4096, 10, "rvo", False) and steps_per_launch == 64:
-            traffic = 425.0 * N * M * steps_per_launch / (launch_ms * 1e-3) / 1e9  # GB/s, comparable to `achieved`
+            traffic = 423.6 * N * M * steps_per_launch / (launch_ms * 1e-3) / 1e9  # GB/s, comparable to `achieved`
         line = {
             "metric": "env-steps/sec (whole node), 4096 worlds x 10 agents",
             "value": value, "unit": "env-steps/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
@@ -176,8 +181,10 @@ def main():
             "agent_steps_per_s": value * M,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_step2<.., true>" if args.per_step_launch else "k_rollout2<256, 10, 5, true>",
-                         "launch_ms": launch_ms, "alg_bytes_per_agent_step": balg},
+                         "kernel": kernel_name,
+                         "launch_ms": launch_ms, "alg_bytes_per_agent_step": balg,
+                         "alg_bytes_per_launch": balg * N * M * steps_per_launch,
+                         "traffic_bytes_per_launch": None if traffic is None else 423.6 * N * M * steps_per_launch},
             "episodes": st,
         }
         if not args.no_cpu_baseline:
