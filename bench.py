@@ -67,6 +67,8 @@ def main():
     ap.add_argument("--per-step-launch", action="store_true", help="one cagym_step launch per env step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pool-factor", type=int, default=8, help="scenario pool size = factor x worlds")
+    ap.add_argument("--scenarios", default="host", choices=["host", "device"],
+                    help="host: numpy rejection sampler + upload; device: cagym_generate_scenarios (same rule)")
     args = ap.parse_args()
 
     import torch
@@ -94,9 +96,12 @@ def main():
     N, M = args.worlds, args.agents
     pol = scen.POLICY_RVO if args.policy == "rvo" else scen.POLICY_NONCOOP
     S = args.pool_factor * N
-    a6 = scen.random_worlds_fast(S, M, seed=1234 + 7919 * rank)
     env = BEnv(N, M, n_scenarios=S, game_over_mode="all", device=device)
-    env.set_scenarios(a6, pol, scen.DYN_UNICYCLE, coop=np.full((S, M), 0.5))
+    if args.scenarios == "device":
+        env.generate_scenarios(seed=1234 + 7919 * rank, ego_policy=pol, other_policies=(pol, pol), p_b=0.0)
+    else:
+        a6 = scen.random_worlds_fast(S, M, seed=1234 + 7919 * rank)
+        env.set_scenarios(a6, pol, scen.DYN_UNICYCLE, coop=np.full((S, M), 0.5))
     env.reset()
 
     ROLL = max(1, min(args.roll, args.steps))

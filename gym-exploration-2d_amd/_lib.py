@@ -35,8 +35,22 @@ class CagymStatePtrs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n, _ in STATE_FIELDS]
 
 
+class CagymGenParams(C.Structure):
+    """cagym_gen_params (include/cagym.h)."""
+    _fields_ = [("seed", C.c_uint64), ("n_min", C.c_int32), ("n_max", C.c_int32), ("ego_policy", C.c_int32),
+                ("ego_dynamics", C.c_int32), ("policy_a", C.c_int32), ("policy_b", C.c_int32),
+                ("other_dynamics", C.c_int32), ("max_tries", C.c_int32), ("p_b", C.c_double), ("side", C.c_double),
+                ("min_travel", C.c_double), ("min_sep", C.c_double), ("radius", C.c_double), ("pref_speed", C.c_double),
+                ("coop", C.c_double)]
+
+
+class CagymScenarioPtrs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("agents6", "policy", "dynamics", "n_agents", "coop")]
+
+
 EXPORTS = ["cagym_version", "cagym_create", "cagym_destroy", "cagym_last_error", "cagym_set_scenarios",
-           "cagym_reset", "cagym_step", "cagym_step_autoreset", "cagym_rollout", "cagym_get_state", "cagym_laserscan"]
+           "cagym_reset", "cagym_step", "cagym_step_autoreset", "cagym_rollout", "cagym_get_state", "cagym_laserscan",
+           "cagym_generate_scenarios", "cagym_get_scenarios"]
 
 _lib = None
 
@@ -65,6 +79,8 @@ def load():
     L.cagym_rollout.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(CagymOutputs), C.c_void_p]
     L.cagym_get_state.argtypes = [C.c_void_p, C.POINTER(CagymStatePtrs)]
     L.cagym_laserscan.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.cagym_generate_scenarios.argtypes = [C.c_void_p, C.POINTER(CagymGenParams), C.POINTER(C.c_int32), C.c_void_p]
+    L.cagym_get_scenarios.argtypes = [C.c_void_p, C.POINTER(CagymScenarioPtrs)]
     _lib = L
     return L
 

@@ -99,6 +99,35 @@ class BatchedCollisionAvoidanceEnv(object):
                                             self._stream())
         _lib.check(self.L, self.h, rc, "cagym_set_scenarios")
 
+    def generate_scenarios(self, seed, n_agents=None, ego_policy=5, ego_dynamics=0, other_policies=(5, 1), p_b=0.5,
+                           other_dynamics=0, side=7.5, min_travel=4.0, min_sep=1.5, radius=0.5, pref_speed=1.0,
+                           coop=0.5, max_tries=100000, check=True):
+        """Fill the scenario pool ON DEVICE with the rule of train_agents_random_positions (test_cases.py:1362-1463):
+        no host sampling, no upload.  n_agents = int or (min, max); agent 0 gets (ego_policy, ego_dynamics), every
+        other agent other_policies[1] with probability p_b else other_policies[0].  Returns the number of agents
+        whose rejection loop hit max_tries (0 in any sane configuration) when check=True."""
+        if n_agents is None:
+            n_agents = self.M
+        n_min, n_max = (n_agents, n_agents) if np.isscalar(n_agents) else n_agents
+        P = _lib.CagymGenParams(int(seed), int(n_min), int(n_max), int(ego_policy), int(ego_dynamics),
+                                int(other_policies[0]), int(other_policies[1]), int(other_dynamics), int(max_tries),
+                                float(p_b), float(side), float(min_travel), float(min_sep), float(radius),
+                                float(pref_speed), float(coop))
+        nf = C.c_int32(0)
+        with torch.cuda.device(self.device):
+            rc = self.L.cagym_generate_scenarios(self.h, C.byref(P), C.byref(nf) if check else None, self._stream())
+        _lib.check(self.L, self.h, rc, "cagym_generate_scenarios")
+        return int(nf.value) if check else None
+
+    def scenarios(self):
+        """Zero-copy device views of the scenario pool: agents6 [S,M,6], policy / dynamics [S,M], n_agents [S], coop."""
+        sp = _lib.CagymScenarioPtrs()
+        _lib.check(self.L, self.h, self.L.cagym_get_scenarios(self.h, C.byref(sp)), "cagym_get_scenarios")
+        S, M = self.S, self.M
+        spec = {"agents6": ((S, M, 6), "f8"), "policy": ((S, M), "i4"), "dynamics": ((S, M), "i4"),
+                "n_agents": ((S,), "i4"), "coop": ((S, M), "f8")}
+        return {k: torch.as_tensor(_DevArray(getattr(sp, k), shp, ts), device=self.device) for k, (shp, ts) in spec.items()}
+
     # ---- gym surface ----------------------------------------------------------------------------
     def _obs(self):
         obs = {"other_agents_states": self.obs_oas, "ego": self.obs_ego}

@@ -12,6 +12,7 @@
 #include "cagym_kernels2.h"
 #include "cagym_ig.h"
 #include "cagym_ga3c.h"
+#include "cagym_gen.h"
 
 namespace {
 
@@ -273,6 +274,63 @@ int cagym_set_scenarios(void* env, const double* agents6, const double* heading0
     // a new pool restarts the episode numbering
     HIPCHK(e, hipMemsetAsync(D.episode, 0, e->cfg.n_worlds * sizeof(int32_t), st));
     e->scenarios_set = true;
+    return CAGYM_OK;
+}
+
+int cagym_generate_scenarios(void* env, const cagym_gen_params* params, int32_t* n_failed_host, void* stream) {
+    Env* e = reinterpret_cast<Env*>(env);
+    if (!e) return fail(nullptr, CAGYM_E_INVALID, "null env");
+    if (!params) return fail(e, CAGYM_E_INVALID, "null params");
+    const cagym_gen_params& P = *params;
+    const int M = e->cfg.max_agents;
+    if (P.n_min < 1 || P.n_max > M || P.n_min > P.n_max) return fail(e, CAGYM_E_INVALID, "need 1 <= n_min <= n_max <= max_agents");
+    const int32_t pols[3] = {P.ego_policy, P.policy_a, P.policy_b};
+    for (int32_t q : pols)
+        if (q < 0 || q > CAGYM_POL_IGMCTS) return fail(e, CAGYM_E_INVALID, "policy id out of range");
+    if (P.ego_dynamics < 0 || P.ego_dynamics > CAGYM_DYN_FIRSTORDER || P.other_dynamics < 0 || P.other_dynamics > CAGYM_DYN_FIRSTORDER)
+        return fail(e, CAGYM_E_INVALID, "dynamics id out of range");
+    if (P.max_tries < 1 || !(P.side > 0) || !(P.p_b >= 0 && P.p_b <= 1)) return fail(e, CAGYM_E_INVALID, "bad generator parameters");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    CagymDev& D = e->D;
+    GenDev G;
+    G.agents6 = const_cast<double*>(D.sc_agents6);
+    G.policy = const_cast<int32_t*>(D.sc_policy);
+    G.dyn = const_cast<int32_t*>(D.sc_dyn);
+    G.nagents = const_cast<int32_t*>(D.sc_nagents);
+    G.coop = const_cast<double*>(D.sc_coop);
+    G.nobst = const_cast<int32_t*>(D.sc_nobst);
+    G.S = e->cfg.n_scenarios;
+    G.M = M;
+    int32_t* d_failed = reinterpret_cast<int32_t*>(D.episode);  // scratch word: the episode counters are rewritten below
+    HIPCHK(e, hipMemsetAsync(d_failed, 0, sizeof(int32_t), st));
+    hipLaunchKernelGGL(k_generate_scenarios, dim3((G.S + 63) / 64), dim3(64), 0, st, G, P, d_failed);
+    HIPCHK(e, hipGetLastError());
+    D.sc_heading0 = nullptr;  // toward the goal (agent.py:29-31)
+    e->any_rvo = (P.ego_policy == CAGYM_POL_RVO || P.policy_a == CAGYM_POL_RVO || P.policy_b == CAGYM_POL_RVO) ? 1 : 0;
+    if (e->cfg.max_obstacles > 0) {  // free space: empty rasters
+        hipLaunchKernelGGL(k_rasterize, dim3((unsigned)G.S), dim3(256), 0, st, e->sc_obst, D.sc_nobst, e->cfg.max_obstacles,
+                           const_cast<uint32_t*>(D.map_bits));
+        HIPCHK(e, hipGetLastError());
+    }
+    if (n_failed_host) {
+        HIPCHK(e, hipMemcpyAsync(n_failed_host, d_failed, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIPCHK(e, hipStreamSynchronize(st));
+    }
+    HIPCHK(e, hipMemsetAsync(D.episode, 0, e->cfg.n_worlds * sizeof(int32_t), st));  // a new pool restarts the episode numbering
+    e->scenarios_set = true;
+    return CAGYM_OK;
+}
+
+int cagym_get_scenarios(void* env, cagym_scenario_ptrs* out) {
+    Env* e = reinterpret_cast<Env*>(env);
+    if (!e) return fail(nullptr, CAGYM_E_INVALID, "null env");
+    if (!out) return fail(e, CAGYM_E_INVALID, "null out");
+    out->agents6 = e->D.sc_agents6;
+    out->policy = e->D.sc_policy;
+    out->dynamics = e->D.sc_dyn;
+    out->n_agents = e->D.sc_nagents;
+    out->coop = e->D.sc_coop;
     return CAGYM_OK;
 }
 

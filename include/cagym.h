@@ -201,6 +201,38 @@ int cagym_ig_rollouts(void* env, const double* pose0, const uint64_t* observed0,
                       int max_steps, int xdt, double dt, double fov_rad, double range, uint64_t seed,
                       double* rewards, uint8_t* actions, double* final_pose, uint64_t* observed_out, void* stream);
 
+/* ---- on-device scenario generation ---------------------------------------------------
+ * train_agents_random_positions (test_cases.py:1362-1463) for every scenario of the pool, one lane per
+ * scenario: per agent draw start x, y and goal x, y ~ U(-side, side) (four draws per attempt, in that order)
+ * until the start is >= min_sep from every earlier start, the goal >= min_sep from every earlier goal
+ * (is_pose_valid, test_cases.py:129-133) and |goal - start| >= min_travel; radius / pref_speed / cooperation
+ * coefficient constant (:1364-1365, :1426).  Agents per scenario ~ U{n_min..n_max} (random.randint(2, n) when
+ * unseeded, n when seeded, :1367-1372).  Agent 0 gets (ego_policy, ego_dynamics); every other agent policy_b
+ * with probability p_b else policy_a (random.choice of two = 0.5, :1417; 0.2 in :1352-1355) and other_dynamics.
+ * Random numbers: counter-based (splitmix64 finaliser on (seed, scenario, draw)), NOT numpy's global MT19937
+ * stream, so agreement with the reference is distributional; the CPU oracle uses the same generator and agrees
+ * bit for bit.  max_tries bounds the rejection loop (the last draw is kept; *n_failed counts such agents). */
+typedef struct cagym_gen_params {
+    uint64_t seed;
+    int32_t n_min, n_max;
+    int32_t ego_policy, ego_dynamics;
+    int32_t policy_a, policy_b, other_dynamics;
+    int32_t max_tries;
+    double p_b;
+    double side, min_travel, min_sep, radius, pref_speed, coop;
+} cagym_gen_params;
+int cagym_generate_scenarios(void* env, const cagym_gen_params* params, int32_t* n_failed_host, void* stream);
+
+/* zero-copy DEVICE views of the scenario pool (parity tests, dataset export) */
+typedef struct cagym_scenario_ptrs {
+    const double* agents6;    /* [S, M, 6] */
+    const int32_t* policy;    /* [S, M]    */
+    const int32_t* dynamics;  /* [S, M]    */
+    const int32_t* n_agents;  /* [S]       */
+    const double* coop;       /* [S, M]    */
+} cagym_scenario_ptrs;
+int cagym_get_scenarios(void* env, cagym_scenario_ptrs* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -29,7 +29,7 @@ class Config(C.Structure):
 
 
 def build(force=False):
-    srcs = [os.path.join(HERE, f) for f in ("cagym_oracle.c", "cagym_oracle_ig.c", "cagym_oracle.h", "Makefile")]
+    srcs = [os.path.join(HERE, f) for f in ("cagym_oracle.c", "cagym_oracle_ig.c", "cagym_oracle_gen.c", "cagym_oracle.h", "Makefile")]
     if force or not os.path.exists(LIB) or any(os.path.getmtime(s) > os.path.getmtime(LIB) for s in srcs):
         subprocess.check_call(["make", "-s", "-C", HERE, "libcagym_oracle.so"])
     return LIB
@@ -70,6 +70,8 @@ def lib():
         L.cao_ig_rollout.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
                                                         C.c_double, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p,
                                                         C.c_void_p, C.c_void_p]
+        L.cao_generate_scenarios.restype = C.c_int
+        L.cao_generate_scenarios.argtypes = [C.c_uint64] + [C.c_int] * 10 + [C.c_double] * 7 + [C.c_void_p] * 5
         _lib = L
     return _lib
 
@@ -224,3 +226,25 @@ def rollout(belief, edf, pose0, observed0, exclude, n_steps, seed, q, sim, xdt=5
     if want_observed:
         return r, acts[:n_steps], pose, obs
     return r, acts[:n_steps], pose
+
+
+GEN_DEFAULTS = dict(n_min=None, n_max=None, ego_policy=5, ego_dynamics=0, policy_a=5, policy_b=1, other_dynamics=0,
+                    max_tries=100000, p_b=0.5, side=7.5, min_travel=4.0, min_sep=1.5, radius=0.5, pref_speed=1.0, coop=0.5)
+
+
+def generate_scenarios(S, M, seed, **kw):
+    """CPU twin of cagym_generate_scenarios (train_agents_random_positions, test_cases.py:1362-1463).
+    Returns (agents6[S,M,6], policy[S,M], dynamics[S,M], n_agents[S], coop[S,M], n_failed)."""
+    P = dict(GEN_DEFAULTS, **kw)
+    n_min = M if P["n_min"] is None else P["n_min"]
+    n_max = M if P["n_max"] is None else P["n_max"]
+    a6 = np.zeros((S, M, 6))
+    pol = np.zeros((S, M), dtype=np.int32)
+    dyn = np.zeros((S, M), dtype=np.int32)
+    na = np.zeros(S, dtype=np.int32)
+    cp = np.zeros((S, M))
+    nf = lib().cao_generate_scenarios(seed, S, M, n_min, n_max, P["ego_policy"], P["ego_dynamics"], P["policy_a"],
+                                      P["policy_b"], P["other_dynamics"], P["max_tries"], P["p_b"], P["side"],
+                                      P["min_travel"], P["min_sep"], P["radius"], P["pref_speed"], P["coop"], _p(a6),
+                                      _p(pol), _p(dyn), _p(na), _p(cp))
+    return a6, pol, dyn, na, cp, nf

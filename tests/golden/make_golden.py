@@ -477,7 +477,7 @@ def ga3c_states():
     print("%-28s          %8.1f KB" % ("ga3c_states", os.path.getsize(path) / 1024))
 
 
-if __name__ == "__main__" and "--dmcts-only" not in sys.argv:
+if __name__ == "__main__" and "--dmcts-only" not in sys.argv and "--scenarios-only" not in sys.argv:
     if "--ga3c-only" in sys.argv:
         ga3c_states()
         sys.exit(0)
@@ -529,3 +529,34 @@ def dmcts_reference(n_seeds=6, n_steps=6):
 
 if "--dmcts-only" in sys.argv:
     dmcts_reference()
+
+
+def scenario_statistics(n_worlds=400, n_agents=10):
+    """Scenarios drawn by the reference's own train_agents_random_positions (test_cases.py:1362-1463), seeded with
+    np.random.seed(k) / random.seed(k) by the function itself.  The third-party rvo2 simulator is absent, so its
+    stand-in module gets a constructor-only PyRVOSimulator (RVOPolicy.__init__, RVOPolicy.py:25-28, builds one);
+    nothing of it is exercised.  The fixture is data: start/goal rows and the policy class drawn for every agent."""
+    import sys as _sys
+    from gym_collision_avoidance.envs import test_cases as tc
+
+    class PyRVOSimulator(object):
+        def __init__(self, *a, **k):
+            pass
+    _sys.modules["rvo2"].PyRVOSimulator = PyRVOSimulator
+    rows = np.zeros((n_worlds, n_agents, 4))
+    noncoop = np.zeros((n_worlds, n_agents), dtype=np.uint8)
+    for w in range(n_worlds):
+        with rh.quiet():
+            agents, _ = tc.train_agents_random_positions(number_of_agents=n_agents, ego_agent_policy=tc.RVOPolicy,
+                                                         seed=w + 1)
+        assert len(agents) == n_agents
+        for i, a in enumerate(agents):
+            rows[w, i] = [a.pos_global_frame[0], a.pos_global_frame[1], a.goal_global_frame[0], a.goal_global_frame[1]]
+            noncoop[w, i] = type(a.policy).__name__ == "NonCooperativePolicy"
+    path = os.path.join(HERE, "scenario_stats.npz")
+    np.savez_compressed(path, rows=rows, noncoop=noncoop)
+    print("%-28s          %8.1f KB" % ("scenario_stats", os.path.getsize(path) / 1024))
+
+
+if "--scenarios-only" in sys.argv:
+    scenario_statistics()

@@ -23,6 +23,7 @@ env.reset()
 for _ in range(150):
     env.step()
 env.ga3c_states()
+orc.generate_scenarios(60, 10, seed=3, n_min=2, n_max=10)
 z = np.load(os.path.join(%(root)r, "tests", "golden", "ig_primitives.npz"))
 edf, d2 = orc.edt(orc.rasterize(z["rects__obstacles"]))
 for p in z["rects__vis_poses"][:10]:
