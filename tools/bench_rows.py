@@ -62,6 +62,16 @@ out["ga3c_state_plus_forward_8192_agents_ms"] = dt_nn * 1e3
 dt_ls = timed(lambda: env.sense_laserscan(), 50)
 out["laserscan_81920_agents_ms"] = dt_ls * 1e3
 env.close()
+# second cfg4 run of SURVEY 8(d): GA3C + LaserScan on ALL agents
+pol_all = np.full((N, M), scen.POLICY_GA3C, dtype=np.int32)
+env = B(N, M, max_obstacles=K, laserscan=True, game_over_mode="agent0")
+env.set_scenarios(a6, pol_all, scen.DYN_UNICYCLE, coop=np.full((N, M), 0.5), obstacles=ob, n_obst=nob)
+env.reset()
+policy = GA3C(env)
+dt = timed(step4, 30)
+out["cfg4b_8192x10_ga3c_all_agents_laserscan_obstacles"] = {"ms_per_step": dt * 1e3, "env_steps_per_s": N / dt,
+                                                           "agent_nn_evals_per_s": N * M / dt}
+env.close()
 # ---- cfg5-style -------------------------------------------------------------------------------------------
 N, M = 2048, 20
 a6 = scen.random_worlds_fast(N, M, seed=4)
@@ -91,4 +101,34 @@ zeros = torch.zeros((Qr, 60), dtype=torch.int64, device=env.device)
 dt = timed(lambda: ig.rollouts(poses[:Qr], zeros, zeros, world[:Qr], torch.full((Qr,), H), torch.full((Qr,), 0.5), nsims, 7), 10)
 out["rollouts_per_s_horizon4"] = Qr * nsims / dt
 out["rollout_visibility_queries_per_s"] = Qr * nsims * H / dt
+env.close()
+# cfg5 env part: 2048 worlds x 20 agents = 3 IG agents (external (v, omega), FirstOrderDynamics) + 2 static
+# targets + 15 NonCooperative, obstacles, OAS [19, 10] observations; per-step launches with external actions
+pol5 = np.full((N, M), scen.POLICY_NONCOOP, dtype=np.int32)
+pol5[:, :3] = scen.POLICY_IGMCTS
+pol5[:, 3:5] = scen.POLICY_STATIC
+dyn5 = np.full((N, M), scen.DYN_UNICYCLE, dtype=np.int32)
+dyn5[:, :3] = scen.DYN_FIRSTORDER
+env = B(N, M, max_obstacles=8, game_over_mode="all")
+env.set_scenarios(a6, pol5, dyn5, obstacles=ob, n_obst=nob)
+env.reset()
+ext5 = torch.zeros((N, M, 2), dtype=torch.float32, device=env.device)
+ext5[:, :3, 0] = 2.0
+dt = timed(lambda: env.step(ext5, auto_reset=True), 100)
+out["cfg5_env_part_2048x20"] = {"ms_per_step": dt * 1e3, "env_steps_per_s": N / dt, "agent_steps_per_s": N * M / dt,
+                                "hbm_frac_917B_per_agent_step": N * M / dt * 917.0 / 8e12}
+# Dec-MCTS planning step for 3 robots per world on 64 worlds, exp/dmcts.py budget (Ntree 30, Nsims 10, horizon 4,
+# Ncycles 5): host tree + device primitives
+dm = importlib.import_module("gym-exploration-2d_amd.dmcts")
+igm = importlib.import_module("gym-exploration-2d_amd.ig")
+ig = IG(env)
+NW = 64
+planner = dm.DecMCTSPlanner(igm.InfoGainBackend(ig), NW, 3, radius=0.5, Ntree=30, Nsims=10, horizon=4, Ncycles=5, seed=1)
+pp = np.concatenate([a6[:NW, :3, 0:2], np.zeros((NW, 3, 1))], axis=2)
+t0 = time.perf_counter()
+planner.plan(pp)
+dtp = time.perf_counter() - t0
+out["dmcts_plan_64_worlds_3_robots_s"] = dtp
+out["dmcts_rollouts_per_s_incl_host_tree"] = NW * 3 * 5 * 30 * 10 / dtp
+env.close()
 print(json.dumps(out, indent=1))
