@@ -318,8 +318,10 @@ __device__ inline void step_core2(const CagymDev& D, const Lds2& W, LaneCtx& C, 
                 const double pref = W.tpref[a];
                 const double sc = pref / norm2(gx, gy);
                 float vx, vy;
+                STAMP(10);  // list read + ego set-up
                 orca_lp_group<GW>(W.sorted, W.proj, a, j, nn, (float)pref, (float)(sc * gx), (float)(sc * gy), vx, vy, AS);
                 if (j == 0) W.lpv[a] = make_float2(vx, vy);
+                STAMP(11);  // LP of group 0's agent
             }
         }
         __syncthreads();

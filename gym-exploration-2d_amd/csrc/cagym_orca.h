@@ -489,11 +489,11 @@ template <int GW>
 __device__ inline void orca_lp_group(const float4* L, float4* P, int a, int j, int nn, float radius, float ox, float oy,
                                      float& rx, float& ry, int stride) {
     const int gbase = (threadIdx.x & 63) & ~(GW - 1);
+    const uint64_t gbits = (1ull << GW) - 1ull;
     const float4 lj = j < nn ? L[j * stride + a] : make_float4(0.f, 0.f, 0.f, 0.f);
-    // every half-plane of the ego in registers up front: one LDS latency instead of one per visited line
-    float4 ln[CAGYM_MAXNB];
-#pragma unroll
-    for (int i = 0; i < CAGYM_MAXNB; i++) ln[i] = L[i * stride + a];  // slots >= nn: stale but in bounds, unused
+    // nn <= GW + 1: half-plane GW (if any) has no lane of its own; lane 0 also watches it
+    const bool extra = j == 0 && GW < nn;
+    const float4 lx = extra ? L[GW * stride + a] : make_float4(0.f, 0.f, 0.f, 0.f);
     if (ox * ox + oy * oy > radius * radius) {
         const float inv = 1.0f / sqrtf(ox * ox + oy * oy);
         rx = ox * inv * radius;
@@ -502,14 +502,23 @@ __device__ inline void orca_lp_group(const float4* L, float4* P, int a, int j, i
         rx = ox;
         ry = oy;
     }
+    // linearProgram2.  The reference walks the lines in order and projects onto each violated one; between two
+    // projections the result does not change, so "the next violated line at or after cur" is one parallel test
+    // (lane j tests half-plane j) + a find-first-set.  The groups of a wave then run linearProgram1 in lockstep,
+    // each on its own line index, instead of diverging over an unrolled loop on i.
     int fail = nn;
-#pragma unroll
-    for (int i = 0; i < CAGYM_MAXNB; i++) {
-        if (i >= fail) continue;  // fail == nn until a line is infeasible
-        const float4 li = ln[i];
-        if (!(detf(li.z, li.w, li.x - rx, li.y - ry) > 0.0f)) continue;
-        if (!orca_lp1_group<GW>(li, lj, j < i, radius, ox, oy, false, gbase, rx, ry))
+    for (int cur = 0; cur < nn;) {  // cur grows by at least 1 per trip: every lane leaves after <= nn trips
+        const bool v1 = j >= cur && j < nn && detf(lj.z, lj.w, lj.x - rx, lj.y - ry) > 0.0f;
+        const bool v2 = extra && GW >= cur && detf(lx.z, lx.w, lx.x - rx, lx.y - ry) > 0.0f;
+        const uint32_t m = (uint32_t)((__ballot(v1) >> gbase) & gbits) | ((uint32_t)((__ballot(v2) >> gbase) & 1ull) << GW);
+        if (!m) break;
+        const int i = __ffs((int)m) - 1;
+        const float4 li = L[i * stride + a];
+        if (!orca_lp1_group<GW>(li, lj, j < i, radius, ox, oy, false, gbase, rx, ry)) {
             fail = i;  // result keeps the value it had before this line (tempResult)
+            break;
+        }
+        cur = i + 1;
     }
     // linearProgram3
     float distance = 0.0f;

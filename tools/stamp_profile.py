@@ -32,8 +32,9 @@ for _ in range(R):
 torch.cuda.synchronize()
 env.L.cagym_debug_stamps(out, 0)
 names = ["S0 publish+bar", "P1a lines+bar", "P1b rank+bar", "S1c post+dynamics+bar", "P2 pairs+bar", "S2 reward/done+bar",
-         "P3 OAS rows+bar", "store", "S1a LP2 per agent+bar", "S1b coop LP3+bar"]
-tot = sum(out[:8]) + out[8] + out[9]
+         "P3 OAS rows+bar", "store", "LP: wait for the other groups + barrier", "-", "LP: list + ego set-up (group 0)",
+         "LP: LP2/LP3 of group 0's agent"]
+tot = sum(out[:12])
 print("s_memtime ticks (100 MHz constant clock?) per step, workgroup 0; total %.1f per step" % (tot / (R * T)))
-for i, n in enumerate(names[:10]):
+for i, n in enumerate(names[:12]):
     print("  %-22s %10.1f  %5.1f %%" % (n, out[i] / (R * T), 100.0 * out[i] / tot))
