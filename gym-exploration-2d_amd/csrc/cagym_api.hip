@@ -76,7 +76,7 @@ CagymOut to_out(const cagym_outputs* o) {
 // worlds per workgroup of the compile-time specialisations (0 = generic: 64 / M worlds, LDS stride 64)
 //   M = 4 : 16 worlds,  96 unordered pairs per phase round of 256 lanes
 //   M = 10:  5 worlds (225 unordered / 500 directed pair slots, ~35 live agents = 2 rounds of 32 LP groups), or
-//            4 worlds while every workgroup of the launch is co-resident (<= 4 per CU): ~28 live agents = one
+//            4 worlds while every workgroup of the launch is co-resident (<= 5 per CU): ~28 live agents = one
 //            round of LP groups; measured 4096 worlds: 259 vs 247 M env-steps/s, 65536 worlds: 342 vs 392
 //   M = 20:  2 worlds, 380 unordered / 800 directed pair slots on 512 lanes
 #define WPW20 2
@@ -171,7 +171,7 @@ int cagym_create(const cagym_config* cfg, void** env_out) {
             int cus = 256;
             if (hipGetDeviceProperties(&prop, e->cfg.device) == hipSuccess && prop.multiProcessorCount > 0)
                 cus = prop.multiProcessorCount;
-            e->wpw10 = (e->cfg.n_worlds + 3) / 4 <= 4 * cus ? 4 : 5;
+            e->wpw10 = (e->cfg.n_worlds + 3) / 4 <= 5 * cus ? 4 : 5;  // 5 workgroups per CU fit (94 VGPRs, 24 KB LDS)
             const char* w = getenv("CAGYM_WPW10");  // diagnostics
             if (w && (w[0] == '4' || w[0] == '5')) e->wpw10 = w[0] - '0';
         }

@@ -72,8 +72,10 @@ __host__ __device__ inline int cagym_as(int M, int wpw) { return wpw > 0 ? ((wpw
 __host__ __device__ inline size_t cagym_lds2_bytes(int M, int AS = 64) {
     const size_t MP = cagym_mp(M);
     size_t head = 20 * AS * 8 + AS * 8 + AS * 4 + AS * 4 + AS * 4 + 32 * 4 + 16 + AS * 8 + AS * 4 + AS * 4 + 16;
-    size_t pre = AS * MP * 4 + AS * MP * 16 + 2 * (size_t)CAGYM_MAXNB * AS * 16;
-    size_t post = 2 * AS * MP * 8 + AS * MP + (size_t)AS * (M - 1) * 40;
+    // pre-move view: dsq, lines (re-used as the linearProgram3 scratch once P1b has sorted them; needs MP >= MAXNB
+    // rows, else a separate block), sorted.  post-move view: keys, gap, hit (the OAS rows go straight to HBM).
+    size_t pre = AS * MP * 4 + AS * (MP > CAGYM_MAXNB ? MP : CAGYM_MAXNB) * 16 + (size_t)CAGYM_MAXNB * AS * 16;
+    size_t post = 2 * AS * MP * 8 + AS * MP;
     return a16(head) + (pre > post ? pre : post);
 }
 
@@ -99,12 +101,11 @@ __device__ __forceinline__ Lds2 carve_lds2(unsigned char* smem, int M, int AS = 
     unsigned char* u = smem + a16(head);
     W.dsq = reinterpret_cast<float*>(u);
     W.lines = reinterpret_cast<float4*>(u + AS * MP * 4);
-    W.sorted = W.lines + AS * MP;
-    W.proj = W.sorted + CAGYM_MAXNB * AS;
+    W.sorted = W.lines + AS * (MP > CAGYM_MAXNB ? MP : CAGYM_MAXNB);
+    W.proj = W.lines;  // the unsorted half-planes are dead once P1b has ranked them
     W.keys = reinterpret_cast<double*>(u);
     W.gap = W.keys + AS * MP;
     W.hit = reinterpret_cast<uint8_t*>(W.gap + AS * MP);
-    W.oas = reinterpret_cast<float*>(W.hit + AS * MP);
     return W;
 }
 
@@ -528,11 +529,14 @@ __device__ inline void step_core2(const CagymDev& D, const Lds2& W, LaneCtx& C, 
         }
         __syncthreads();
     }
+    // every (agent, other slot) lane owns exactly one 40-B row of the agent's [K, 10] table and stores it straight to
+    // HBM (five 8-B stores; the workgroup's rows are one contiguous 3600 B x worlds block, merged in L2)
+    if (out.obs_oas)
     for (int p = tid; p < npairs; p += NT) {
         const PairIdx q = pair_of(p, M, inv_m);
-        if (q.j == q.sl) continue;
+        if (q.j == q.sl || q.wl >= C.worlds_valid) continue;
         const int n = W.wn[q.wl];
-        float* my = W.oas + (size_t)q.a * K * 10;
+        float* my = out.obs_oas + ((size_t)blockIdx.x * C.wpw * M + q.a) * K * 10;
         const double kj = W.keys[q.a * MP + q.j];
         float v[10];
         int row;
@@ -568,17 +572,8 @@ __device__ inline void step_core2(const CagymDev& D, const Lds2& W, LaneCtx& C, 
 #pragma unroll
         for (int c = 0; c < 5; c++) r2[c] = make_float2(v[2 * c], v[2 * c + 1]);
     }
-    __syncthreads();
     STAMP(6);
-    // ---- store: the staged OAS table as contiguous 16-B lanes, ego observation from the agent lanes --------
-    if (out.obs_oas) {
-        const size_t world0 = (size_t)blockIdx.x * C.wpw;
-        const int per_world4 = M * K * 10 / 4;
-        const float4* src = reinterpret_cast<const float4*>(W.oas);
-        float4* dst = reinterpret_cast<float4*>(out.obs_oas) + world0 * per_world4;
-        const int total4 = C.worlds_valid * per_world4;
-        for (int q = tid; q < total4; q += NT) dst[q] = src[q];
-    }
+    // ---- ego observation from the agent lanes ---------------------------------------------------------
     if (agent_lane && C.valid) {
         const int nobs = C.active ? C.n - 1 : 0;
         D.n_observed[aidx] = nobs;
