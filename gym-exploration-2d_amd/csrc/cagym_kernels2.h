@@ -55,7 +55,6 @@ struct Lds2 {
     float* dsq;      // [64*MP]   squared centre distance ego->neighbour (+inf = not a neighbour)
     float4* lines;   // [64*MP]   half-plane of (ego, neighbour), unsorted
     float4* sorted;  // [10][64]  half-planes nearest-first
-    float4* proj;    // [10][64]  linearProgram3 scratch
     // union, post-move view
     double* keys;  // [64*MP]   OAS sort key (-inf = not observed)
     double* gap;   // [64*MP]   d - (r_i + r_j) for the lower index of a pair, else +inf
@@ -72,9 +71,9 @@ __host__ __device__ inline int cagym_as(int M, int wpw) { return wpw > 0 ? ((wpw
 __host__ __device__ inline size_t cagym_lds2_bytes(int M, int AS = 64) {
     const size_t MP = cagym_mp(M);
     size_t head = 20 * AS * 8 + AS * 8 + AS * 4 + AS * 4 + AS * 4 + 32 * 4 + 16 + AS * 8 + AS * 4 + AS * 4 + 16;
-    // pre-move view: dsq, lines (re-used as the linearProgram3 scratch once P1b has sorted them; needs MP >= MAXNB
-    // rows, else a separate block), sorted.  post-move view: keys, gap, hit (the OAS rows go straight to HBM).
-    size_t pre = AS * MP * 4 + AS * (MP > CAGYM_MAXNB ? MP : CAGYM_MAXNB) * 16 + (size_t)CAGYM_MAXNB * AS * 16;
+    // pre-move view: dsq, lines (an ego's row doubles as its linearProgram3 scratch once its group has sorted it),
+    // sorted.  post-move view: keys, gap, hit (the OAS rows go straight to HBM).
+    size_t pre = AS * MP * 4 + AS * MP * 16 + (size_t)CAGYM_MAXNB * AS * 16;
     size_t post = 2 * AS * MP * 8 + AS * MP;
     return a16(head) + (pre > post ? pre : post);
 }
@@ -101,8 +100,7 @@ __device__ __forceinline__ Lds2 carve_lds2(unsigned char* smem, int M, int AS = 
     unsigned char* u = smem + a16(head);
     W.dsq = reinterpret_cast<float*>(u);
     W.lines = reinterpret_cast<float4*>(u + AS * MP * 4);
-    W.sorted = W.lines + AS * (MP > CAGYM_MAXNB ? MP : CAGYM_MAXNB);
-    W.proj = W.lines;  // the unsorted half-planes are dead once P1b has ranked them
+    W.sorted = W.lines + AS * MP;
     W.keys = reinterpret_cast<double*>(u);
     W.gap = W.keys + AS * MP;
     W.hit = reinterpret_cast<uint8_t*>(W.gap + AS * MP);
@@ -281,24 +279,6 @@ __device__ inline void step_core2(const CagymDev& D, const Lds2& W, LaneCtx& C, 
         }
         __syncthreads();
         STAMP(1);
-        for (int p = tid; p < npairs; p += NT) {
-            const PairIdx q = pair_of(p, M, inv_m);
-            const float dq = W.dsq[q.a * MP + q.j];
-            if (!(dq < INFINITY)) continue;
-            // rank among the ego's neighbours: nearest first, ties by lower index (Agent::insertAgentNeighbor)
-            int rank = 0;
-            const float4* row = reinterpret_cast<const float4*>(W.dsq + q.a * MP);
-            for (int l4 = 0; l4 < MP; l4 += 4) {
-                const float4 v = row[l4 >> 2];
-                rank += (v.x < dq) || (v.x == dq && l4 + 0 < q.j);
-                rank += (v.y < dq) || (v.y == dq && l4 + 1 < q.j);
-                rank += (v.z < dq) || (v.z == dq && l4 + 2 < q.j);
-                rank += (v.w < dq) || (v.w == dq && l4 + 3 < q.j);
-            }
-            if (rank < CAGYM_MAXNB) W.sorted[rank * AS + q.a] = W.lines[q.a * MP + q.j];
-        }
-        __syncthreads();
-        STAMP(2);
     }
     // ---- S1: _take_action (env.py:287-340).  RVO: linearProgram2 (+ linearProgram3 when infeasible) of every
     //      live RVO agent on a GW-lane group, lane j <-> half-plane j; the agents come from the compact list the
@@ -314,13 +294,33 @@ __device__ inline void step_core2(const CagymDev& D, const Lds2& W, LaneCtx& C, 
                 const int wl = (int)__umulhi((uint32_t)a, inv_m);
                 const int n = W.wn[wl];
                 const int nn = (n - 1) < CAGYM_MAXNB ? (n - 1) : CAGYM_MAXNB;
+                // the group ranks its ego's neighbours (nearest first, ties by lower index: Agent::insertAgentNeighbor)
+                // and scatters the half-planes into sorted order; producer and consumer are the same wave, whose LDS
+                // operations execute in order, so no barrier separates the scatter from the reads below
+                {
+                    const float4* row = reinterpret_cast<const float4*>(W.dsq + a * MP);
+                    for (int sl = j; sl < M; sl += GW) {
+                        const float dq = W.dsq[a * MP + sl];
+                        if (!(dq < INFINITY)) continue;
+                        int rank = 0;
+                        for (int l4 = 0; l4 < MP; l4 += 4) {
+                            const float4 v = row[l4 >> 2];
+                            rank += (v.x < dq) || (v.x == dq && l4 + 0 < sl);
+                            rank += (v.y < dq) || (v.y == dq && l4 + 1 < sl);
+                            rank += (v.z < dq) || (v.z == dq && l4 + 2 < sl);
+                            rank += (v.w < dq) || (v.w == dq && l4 + 3 < sl);
+                        }
+                        if (rank < CAGYM_MAXNB) W.sorted[rank * AS + a] = W.lines[a * MP + sl];
+                    }
+                }
                 // prefVelocity and maxSpeed of the ego (RVOPolicy.py:65-85), as orca_ego
                 const double gx = W.tgx[a] - W.tpx[a], gy = W.tgy[a] - W.tpy[a];
                 const double pref = W.tpref[a];
                 const double sc = pref / norm2(gx, gy);
                 float vx, vy;
                 STAMP(10);  // list read + ego set-up
-                orca_lp_group<GW>(W.sorted, W.proj, a, j, nn, (float)pref, (float)(sc * gx), (float)(sc * gy), vx, vy, AS);
+                // linearProgram3 scratch: the ego's own (now dead) row of unsorted half-planes, MP >= nn entries
+                orca_lp_group<GW>(W.sorted, W.lines + a * MP, a, j, nn, (float)pref, (float)(sc * gx), (float)(sc * gy), vx, vy, AS);
                 if (j == 0) W.lpv[a] = make_float2(vx, vy);
                 STAMP(11);  // LP of group 0's agent
             }

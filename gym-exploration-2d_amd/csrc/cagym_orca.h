@@ -484,7 +484,8 @@ __device__ __forceinline__ bool orca_lp1_group(const float4 ln, const float4 min
 }
 
 // Agent::computeNewVelocity after the half-planes exist: linearProgram2 on the nn sorted lines of agent column `a`
-// with optimisation velocity (ox, oy), then linearProgram3 from the failing line when infeasible.
+// with optimisation velocity (ox, oy), then linearProgram3 from the failing line when infeasible (P: private
+// scratch of >= nn - 1 projected lines).
 template <int GW>
 __device__ inline void orca_lp_group(const float4* L, float4* P, int a, int j, int nn, float radius, float ox, float oy,
                                      float& rx, float& ry, int stride) {
@@ -545,7 +546,7 @@ __device__ inline void orca_lp_group(const float4* L, float4* P, int a, int j, i
             const float inv = 1.0f / sqrtf(ddx * ddx + ddy * ddy);
             pj.z = ddx * inv;
             pj.w = ddy * inv;
-            if (have) P[j * stride + a] = pj;
+            if (have) P[j] = pj;
         }
         const uint32_t hmask = (uint32_t)((__ballot(have) >> gbase) & ((1ull << GW) - 1ull));
         const float px = -li.w, py = li.z;
@@ -554,7 +555,7 @@ __device__ inline void orca_lp_group(const float4* L, float4* P, int a, int j, i
         bool failed = false;
         for (int k = 0; k < i; k++) {
             if (!((hmask >> k) & 1u)) continue;
-            const float4 pk = P[k * stride + a];
+            const float4 pk = P[k];
             if (!(detf(pk.z, pk.w, pk.x - qx, pk.y - qy) > 0.0f)) continue;
             if (!orca_lp1_group<GW>(pk, pj, j < k && have, radius, px, py, true, gbase, qx, qy)) {
                 failed = true;
