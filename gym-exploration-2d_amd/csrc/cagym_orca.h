@@ -428,19 +428,37 @@ __device__ __forceinline__ float dpp_f32(float v) {
 #define CAGYM_DPP_QUAD_XOR2 0x4E   // quad_perm [2,3,0,1]
 #define CAGYM_DPP_ROW_MIRROR 0x140
 #define CAGYM_DPP_ROW_HALF_MIRROR 0x141
+// One reduction level = ONE instruction: v_max/min_f32 with a DPP source operand (the builtin route costs a DPP
+// move plus canonicalising maxes per level).  s_nop 1 covers the VALU-write -> DPP-read hazard, which the
+// compiler's hazard recogniser does not see inside inline assembly.  Operands are never NaN here.
+#define CAGYM_DPP_OP(name, op, ctrl)                                                            \
+    __device__ __forceinline__ float name(float v) {                                           \
+        float r;                                                                               \
+        asm volatile("s_nop 1\n\t" op " %0, %1, %1 " ctrl " row_mask:0xf bank_mask:0xf"       \
+                     : "=&v"(r) : "v"(v));                                                    \
+        return r;                                                                              \
+    }
+CAGYM_DPP_OP(dpp_max_row_mirror, "v_max_f32_dpp", "row_mirror")
+CAGYM_DPP_OP(dpp_max_half_mirror, "v_max_f32_dpp", "row_half_mirror")
+CAGYM_DPP_OP(dpp_max_quad2, "v_max_f32_dpp", "quad_perm:[2,3,0,1]")
+CAGYM_DPP_OP(dpp_max_quad1, "v_max_f32_dpp", "quad_perm:[1,0,3,2]")
+CAGYM_DPP_OP(dpp_min_row_mirror, "v_min_f32_dpp", "row_mirror")
+CAGYM_DPP_OP(dpp_min_half_mirror, "v_min_f32_dpp", "row_half_mirror")
+CAGYM_DPP_OP(dpp_min_quad2, "v_min_f32_dpp", "quad_perm:[2,3,0,1]")
+CAGYM_DPP_OP(dpp_min_quad1, "v_min_f32_dpp", "quad_perm:[1,0,3,2]")
 template <int GW>
 __device__ __forceinline__ float grp_max(float v) {
-    if (GW >= 16) v = fmaxf(v, dpp_f32<CAGYM_DPP_ROW_MIRROR>(v));
-    if (GW >= 8) v = fmaxf(v, dpp_f32<CAGYM_DPP_ROW_HALF_MIRROR>(v));
-    v = fmaxf(v, dpp_f32<CAGYM_DPP_QUAD_XOR2>(v));
-    return fmaxf(v, dpp_f32<CAGYM_DPP_QUAD_XOR1>(v));
+    if (GW >= 16) v = dpp_max_row_mirror(v);
+    if (GW >= 8) v = dpp_max_half_mirror(v);
+    v = dpp_max_quad2(v);
+    return dpp_max_quad1(v);
 }
 template <int GW>
 __device__ __forceinline__ float grp_min(float v) {
-    if (GW >= 16) v = fminf(v, dpp_f32<CAGYM_DPP_ROW_MIRROR>(v));
-    if (GW >= 8) v = fminf(v, dpp_f32<CAGYM_DPP_ROW_HALF_MIRROR>(v));
-    v = fminf(v, dpp_f32<CAGYM_DPP_QUAD_XOR2>(v));
-    return fminf(v, dpp_f32<CAGYM_DPP_QUAD_XOR1>(v));
+    if (GW >= 16) v = dpp_min_row_mirror(v);
+    if (GW >= 8) v = dpp_min_half_mirror(v);
+    v = dpp_min_quad2(v);
+    return dpp_min_quad1(v);
 }
 
 // linearProgram1 on the group: half-plane `ln` against the lanes' own lines (`mine`, taking part when `take`).
@@ -454,12 +472,11 @@ __device__ __forceinline__ bool orca_lp1_group(const float4 ln, const float4 min
     const float sq = sqrtf(disc);
     float tl = -dot - sq, tr = -dot + sq;
     float ltl = -INFINITY, ltr = INFINITY;
-    bool lfail = false;
     if (take) {
         const float den = detf(ln.z, ln.w, mine.z, mine.w);
         const float num = detf(mine.z, mine.w, ln.x - mine.x, ln.y - mine.y);
         if (fabsf(den) <= RVO_EPS) {
-            lfail = num < 0.0f;
+            if (num < 0.0f) ltl = INFINITY;  // "parallel and outside": forces tLeft > tRight below, i.e. infeasible
         } else {
             const float t = num / den;
             if (den >= 0.0f) ltr = t;
@@ -468,8 +485,7 @@ __device__ __forceinline__ bool orca_lp1_group(const float4 ln, const float4 min
     }
     tl = fmaxf(tl, grp_max<GW>(ltl));
     tr = fminf(tr, grp_min<GW>(ltr));
-    const bool anyfail = ((__ballot(lfail) >> gbase) & ((1ull << GW) - 1ull)) != 0ull;
-    if (anyfail || tl > tr) return false;
+    if (tl > tr) return false;
     float t;
     if (dir_opt) {
         t = (ox * ln.z + oy * ln.w > 0.0f) ? tr : tl;
