@@ -167,11 +167,11 @@ def main():
                                         spec.get(M, "256, 0, 0" if M <= 12 else "512, 0, 0"))
         achieved = balg * N * M * steps_per_launch / (launch_ms * 1e-3) / 1e9
         # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate
-        # rocprofv3 --pmc passes; profiles/r1/bench_4096x10_rvo_pmc_hbm.txt): 423.6 B per agent-step, measured on
+        # rocprofv3 --pmc passes; profiles/r1/bench_4096x10_rvo_pmc_hbm.txt): 423.9 B per agent-step, measured on
         # this workload at 64 steps per launch; not re-measured live, so null for any other shape.
         traffic = None
         if (N, M, args.policy, args.per_step_launch) == (4096, 10, "rvo", False) and steps_per_launch == 64:
-            traffic = 423.6 * N * M * steps_per_launch / (launch_ms * 1e-3) / 1e9  # GB/s, comparable to `achieved`
+            traffic = 423.9 * N * M * steps_per_launch / (launch_ms * 1e-3) / 1e9  # GB/s, comparable to `achieved`
         line = {
             "metric": "env-steps/sec (whole node), 4096 worlds x 10 agents",
             "value": value, "unit": "env-steps/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
@@ -189,7 +189,7 @@ def main():
                          "kernel": kernel_name,
                          "launch_ms": launch_ms, "alg_bytes_per_agent_step": balg,
                          "alg_bytes_per_launch": balg * N * M * steps_per_launch,
-                         "traffic_bytes_per_launch": None if traffic is None else 423.6 * N * M * steps_per_launch},
+                         "traffic_bytes_per_launch": None if traffic is None else 423.9 * N * M * steps_per_launch},
             "episodes": st,
         }
         if not args.no_cpu_baseline:
