@@ -17,12 +17,31 @@ Reference behaviour restated (paths under gym_collision_avoidance/envs/policies/
                                distributions, grow Ntree times, publish; action = first action of the best path
   ig_mcts.py:234-241           mcts_reward = MI(own observed cells minus cells observed in the sampled plans of
                                the other robots) on the current belief
-Random numbers come from a seeded numpy Generator (plan sampling) and the counter-based device RNG (roll-outs);
-the reference uses the global np.random stream, so only statistical agreement is possible.
+Random numbers are counter-based (splitmix64 finaliser) for both the plan sampling and the roll-outs; the reference
+uses the global np.random stream, so only statistical agreement with it is possible.  This host
+planner is also the executable specification of the device tree (csrc/cagym_dmcts.h, cagym_dmcts_plan): same
+generator keys, same summation orders, same tie rules -- the two make identical decisions (tests/test_dmcts.py).
 """
 import math
 
 import numpy as np
+
+_M64 = (1 << 64) - 1
+
+
+def _mix64(z):
+    z = (z + 0x9E3779B97F4A7C15) & _M64
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
+    return z ^ (z >> 31)
+
+
+def _u01(seed, a, b):
+    """U[0,1) with 53 bits from the counter (a, b) -- identical to gen_u01 / ig_mix64 on the device."""
+    return float(_mix64((seed & _M64) ^ _mix64(((a & 0xFFFFFFFF) << 32) | (b & 0xFFFFFFFF))) >> 11) * 2.0 ** -53
+
+
+PLAN_STREAM = 0x5DEECE66D  # xor-ed into the seed for the plan-sampling stream (distinct from the roll-out stream)
 
 PRIMITIVES = np.array([[v, w] for v in (0.0, 2.0, 4.0) for w in (-0.5 * np.pi, 0.0, 0.5 * np.pi)])  # ig_mcts.py:247-253
 
@@ -60,7 +79,7 @@ class _Tree(object):
                 else:
                     # log(n_p) with n_p == 0 raises in the reference only when every child was visited, which
                     # cannot happen before the parent itself was back-propagated (N >= 1)
-                    u = ch.mu + 2 * self.c_p * (2 * math.log(n_p) / ch.N) ** 0.5 if n_p > 0 else ch.mu
+                    u = ch.mu + 2 * self.c_p * math.sqrt(2 * math.log(n_p) / ch.N) if n_p > 0 else ch.mu
                 if u > best_u:
                     best, best_u = ch, u
             node = best
@@ -79,11 +98,14 @@ class _Tree(object):
         # _update_distribution: top comm_n by mu among non-root nodes (stable for ties: first created first)
         cand = sorted(self.nodes[1:], key=lambda n: -n.mu)[:self.comm_n]
         cand = [n for n in cand if n.has_rollout]
-        q = np.array([n.mu ** 2 for n in cand], dtype=np.float64)
         if len(cand) == 0:
             return
-        q = np.full(len(cand), 1.0 / len(cand)) if q.sum() == 0 else q / q.sum()
-        self.dist = [(n.best_actions, n.best_observed, float(w)) for n, w in zip(cand, q)]
+        q = [n.mu * n.mu for n in cand]
+        tot = 0.0
+        for x in q:  # sequential sum: the device tree adds in the same order
+            tot += x
+        q = [1.0 / len(cand)] * len(cand) if tot == 0 else [x / tot for x in q]
+        self.dist = [(n.best_actions, n.best_observed, w) for n, w in zip(cand, q)]
 
 
 class DecMCTSPlanner(object):
@@ -102,10 +124,20 @@ class DecMCTSPlanner(object):
         self.be, self.N, self.R = backend, int(n_worlds), int(n_robots)
         self.radius, self.Ntree, self.Nsims, self.horizon = float(radius), int(Ntree), int(Nsims), int(horizon)
         self.c_p, self.gamma, self.Ncycles, self.comm_n = float(c_p), float(gamma), int(Ncycles), int(comm_n)
-        self.rng = np.random.default_rng(seed)
         self.seed = int(seed)
         self.calls = 0
         self.trees = None
+        self.published = None
+
+    def reset(self, worlds=None):
+        """Forget the communicated plans (new episode: the reference builds new policy objects).  worlds: indices or
+        None for all."""
+        if self.published is None or worlds is None:
+            self.published = None
+            return
+        for r in range(self.R):
+            for w in worlds:
+                self.published[r][w] = None
 
     # -- batched helpers -----------------------------------------------------------------------------
     def _expand(self, leaves):
@@ -131,9 +163,19 @@ class DecMCTSPlanner(object):
         for w, t in enumerate(trees):
             # sample one plan per other robot from its communicated distribution (_get_system_state)
             excl = np.zeros(60, dtype=np.uint64)
-            for other, dist in t.comms.items():
-                p = np.array([d[2] for d in dist])
-                excl |= dist[self.rng.choice(len(dist), p=p / p.sum())][1]
+            for other in sorted(t.comms):
+                dist = t.comms[other]
+                tot = 0.0
+                for d in dist:
+                    tot += d[2]
+                thr = _u01(self.seed ^ PLAN_STREAM, w, ((self.calls + 1) << 4) | other) * tot
+                pick, run = len(dist) - 1, 0.0
+                for k, d in enumerate(dist):
+                    run += d[2]
+                    if run > thr:
+                        pick = k
+                        break
+                excl |= dist[pick][1]
             sel.append((w, t, t.select(), excl))
         self._expand([(w, t, n) for (w, t, n, _) in sel])
         Q = len(sel)
@@ -148,8 +190,12 @@ class DecMCTSPlanner(object):
         for q, (w, t, n, _) in enumerate(sel):
             r = rew[q]
             b = int(np.argmax(r))  # `if rew > best_reward` keeps the first maximum
+            acc = 0.0
+            for x in r:  # sequential mean (numpy's pairwise sum differs in the last bit)
+                acc += float(x)
+            avg = acc / len(r)
             tail = [int(a) if a != 255 else -1 for a in acts[q, b, :steps[q]]]  # -1: infeasible draw -> (0, 0) action
-            t.backprop(n, float(r.mean()), float(r[b]), n.actions + tail, obs[q, b], self.gamma)
+            t.backprop(n, avg, float(r[b]), n.actions + tail, obs[q, b], self.gamma)
 
     # -- ig_mcts.find_next_action for every robot of every world ------------------------------------------
     def plan(self, poses):
@@ -159,11 +205,17 @@ class DecMCTSPlanner(object):
         trees = [[_Tree(poses[w, r], self.horizon, self.c_p, self.comm_n) for w in range(self.N)] for r in range(self.R)]
         for r in range(self.R):  # Tree.__init__ expands the root
             self._expand([(w, t, t.root) for w, t in enumerate(trees[r])])
-        published = [[None] * self.N for _ in range(self.R)]
+        # best_paths of the previous planning step stay on the policy objects (ig_mcts.py:99-101, 109): the first
+        # cycle of a new step hears the other robots' previous plans.  Q15: a robot listens to agents[j] for
+        # j in range(number of OTHER IG agents), its own entry being overwritten by its node state
+        # (DecMCTS.py:190-191) -- with R robots nobody hears robot R-1.  Reproduced.
+        if self.published is None:
+            self.published = [[None] * self.N for _ in range(self.R)]
+        published = self.published
         for cycle in range(self.Ncycles):
             for r in range(self.R):  # robots in index order; a robot sees what the earlier ones just published
                 for w in range(self.N):
-                    for other in range(self.R):
+                    for other in range(self.R - 1):
                         if other != r and published[other][w] is not None:
                             trees[r][w].comms[other] = published[other][w]
                 for _ in range(self.Ntree):

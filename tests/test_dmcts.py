@@ -111,11 +111,13 @@ def test_statistics_match_reference_dmcts_loop():
     ref = np.load(os.path.join(ROOT, "tests", "golden", "ig_dmcts_reference.npz"))
     rc = ref["cum_reward"]  # [seeds, steps + 1]
     edf = _ig_world()
-    mine = np.array([_run_pipeline(s, rc.shape[1] - 1, lambda e, b: OracleBackend(e, b), edf)[0] for s in range(4)])
+    mine = np.array([_run_pipeline(s, rc.shape[1] - 1, lambda e, b: OracleBackend(e, b), edf)[0] for s in range(8)])
     # step 1 is planner-independent: same belief update + MI as the reference
     assert np.abs(mine[:, 1] - rc[:, 1].mean()).max() < 1e-9 and np.ptp(rc[:, 1]) < 1e-9
     # afterwards the planners use different random streams: the mean cumulative team reward must agree
-    spread = max(3 * rc[:, -1].std(), 0.05 * rc[:, -1].mean())
+    # (16 seeds of this planner: 11.81 +- 0.31; 6 seeds of the reference: 11.95 +- 0.19.  Without the reference's
+    # communication pattern -- previous-step plans heard in the first cycle, Q15 listening graph -- it is 11.62.)
+    spread = 3 * np.sqrt(rc[:, -1].var() / len(rc) + mine[:, -1].var() / len(mine))
     assert abs(mine[:, -1].mean() - rc[:, -1].mean()) < spread, (mine[:, -1], rc[:, -1])
     assert (np.diff(mine, axis=1) > 0).all()  # every step observes something new
     # actions are motion primitives, and the robots do move
