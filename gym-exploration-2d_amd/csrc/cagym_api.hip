@@ -13,6 +13,7 @@
 #include "cagym_ig.h"
 #include "cagym_ga3c.h"
 #include "cagym_gen.h"
+#include "cagym_dmcts.h"
 
 namespace {
 
@@ -610,6 +611,46 @@ int cagym_ig_rollouts(void* env, const double* pose0, const uint64_t* observed0,
                        reinterpret_cast<const unsigned long long*>(exclude), world, n_steps, radius, nsims, max_steps, xdt,
                        dt, fov_rad, range, (unsigned long long)seed, rewards, actions, final_pose,
                        reinterpret_cast<unsigned long long*>(observed_out));
+    HIPCHK(e, hipGetLastError());
+    return CAGYM_OK;
+}
+
+namespace {
+inline int dm_node_cap(const cagym_dmcts_params& p) { return 1 + 9 * (p.Ntree * p.Ncycles + 1); }
+inline size_t dm_align(size_t x) { return (x + 255) & ~(size_t)255; }
+}  // namespace
+
+size_t cagym_dmcts_workspace_bytes(int n_worlds, const cagym_dmcts_params* p) {
+    if (!p || n_worlds < 1 || p->n_robots < 1 || p->Ntree < 1 || p->Ncycles < 1) return 0;
+    const size_t trees = (size_t)n_worlds * p->n_robots;
+    return dm_align(trees * sizeof(DmPublished)) + dm_align(trees * sizeof(int32_t)) + trees * (size_t)dm_node_cap(*p) * sizeof(DmNode);
+}
+
+int cagym_dmcts_plan(void* env, const cagym_dmcts_params* params, const double* poses, void* workspace,
+                     size_t workspace_bytes, double* actions, uint8_t* paths, double* stats, void* stream) {
+    Env* e = reinterpret_cast<Env*>(env);
+    int rc = ig_check(e, "cagym_dmcts_plan");
+    if (rc) return rc;
+    if (!params || !poses || !workspace || !actions || !paths || !stats) return fail(e, CAGYM_E_INVALID, "null argument");
+    const cagym_dmcts_params& p = *params;
+    if (p.n_robots < 1 || p.n_robots > DM_MAXR || p.horizon < 1 || p.horizon > DM_MAXH || p.Nsims < 1 || p.Nsims > DM_MAXSIMS ||
+        p.comm_n < 1 || p.comm_n > DM_MAXCOMM || p.Ntree < 1 || p.Ncycles < 1 || p.xdt < 1 || p.xdt > 1000 ||
+        (size_t)p.Ntree * p.Ncycles > 100000)
+        return fail(e, CAGYM_E_INVALID, "Dec-MCTS parameters out of range (n_robots<=8, horizon<=8, Nsims<=32, comm_n<=8)");
+    const int N = e->cfg.n_worlds;
+    if (workspace_bytes < cagym_dmcts_workspace_bytes(N, params)) return fail(e, CAGYM_E_INVALID, "workspace too small");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const size_t trees = (size_t)N * p.n_robots;
+    unsigned char* base = reinterpret_cast<unsigned char*>(workspace);
+    DmPublished* pub = reinterpret_cast<DmPublished*>(base);
+    int32_t* nn = reinterpret_cast<int32_t*>(base + dm_align(trees * sizeof(DmPublished)));
+    DmNode* nodes = reinterpret_cast<DmNode*>(base + dm_align(trees * sizeof(DmPublished)) + dm_align(trees * sizeof(int32_t)));
+    if (p.reset_comms) HIPCHK(e, hipMemsetAsync(pub, 0, trees * sizeof(DmPublished), st));
+    DmParams P;
+    P.R = p.n_robots; P.Ntree = p.Ntree; P.Nsims = p.Nsims; P.horizon = p.horizon; P.Ncycles = p.Ncycles; P.comm_n = p.comm_n;
+    P.node_cap = dm_node_cap(p); P.xdt = p.xdt; P.call_base = p.call_base;
+    P.c_p = p.c_p; P.gamma = p.gamma; P.radius = p.radius; P.dt = p.dt; P.fov = p.fov_rad; P.range = p.range; P.seed = p.seed;
+    hipLaunchKernelGGL(k_dmcts_plan, dim3((unsigned)N), dim3(DM_THREADS), 0, st, e->G, P, poses, nodes, nn, pub, actions, paths, stats);
     HIPCHK(e, hipGetLastError());
     return CAGYM_OK;
 }

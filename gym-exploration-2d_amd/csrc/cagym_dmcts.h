@@ -1,0 +1,330 @@
+// cagym_dmcts.h -- Dec-MCTS planning step on the device (include/cagym.h: cagym_dmcts_plan).
+//
+// One 128-lane workgroup plans for all IG robots of one world: the UCT tree of every robot (selection, expansion,
+// roll-outs, discounted back-propagation), the top-n action distribution and its exchange between the robots of the
+// world.  Restates pydecmcts/DecMCTS.py:14-18, 92-231, 273-360 and ig_mcts.py:79-109 (reference paths under
+// gym_collision_avoidance/envs/policies/); the executable specification is gym-exploration-2d_amd/dmcts.py
+// (DecMCTSPlanner, host tree over the same device primitives): generator keys, summation orders and tie rules are
+// the same, and the two make identical decisions (tests/test_dmcts.py).
+//
+// Tree bookkeeping is a few scalar operations per grow and runs on lane 0; what costs time -- visibility sets of
+// new children, the Nsims x (horizon - stage) roll-out steps, the MI rewards, the top-n scan -- is spread over the
+// workgroup with the functions of cagym_ig.h (so the numbers are those of cagym_ig_rollouts bit for bit).
+#pragma once
+#include "cagym_ig.h"
+
+#define DM_MAXH 8      // horizon
+#define DM_MAXCOMM 8   // communicated plans per robot
+#define DM_MAXR 8      // IG robots per world
+#define DM_MAXSIMS 32
+#define DM_THREADS 128
+#define DM_NOACT 255   // no action stored
+#define DM_INFEAS 254  // infeasible random draw: the roll-out appended (0, 0) (ig_mcts.py:226-231)
+
+struct DmNode {
+    double mu, Nv, best;
+    double pose[3];
+    int32_t parent, child0;
+    uint8_t nchild, stage, has_roll, seq_len;
+    uint8_t acts[DM_MAXH];  // own action sequence from the root (stage entries)
+    uint8_t seq[DM_MAXH];   // best roll-out through this node: full action sequence from the root (seq_len entries)
+    uint32_t pad;
+    unsigned long long observed[IG_BEL];  // cells observed on the way to this node
+    unsigned long long best_obs[IG_BEL];  // cells observed along the best roll-out through this node
+};
+
+// What a robot has communicated (ActionDistribution, DecMCTS.py:25-60): kept across planning steps.
+struct DmPublished {
+    int32_t n, seq_len;
+    double q[DM_MAXCOMM];
+    uint8_t seq0[DM_MAXH];  // action sequence of the best entry
+    unsigned long long obs[DM_MAXCOMM][IG_BEL];
+};
+
+struct DmParams {
+    int R, Ntree, Nsims, horizon, Ncycles, comm_n, node_cap, xdt;
+    unsigned int call_base;
+    double c_p, gamma, radius, dt, fov, range;
+    unsigned long long seed;
+};
+
+__device__ __forceinline__ double dm_u01(unsigned long long seed, unsigned int a, unsigned int b) {
+    const unsigned long long h = ig_mix64(seed ^ ig_mix64(((unsigned long long)a << 32) | (unsigned long long)b));
+    return (double)(h >> 11) * 0x1.0p-53;
+}
+
+__device__ __forceinline__ void dm_prim(int k, double& v, double& w) {  // mcts_avail_actions (ig_mcts.py:247-253)
+    v = k / 3 == 0 ? 0.0 : (k / 3 == 1 ? 2.0 : 4.0);
+    w = k % 3 == 0 ? -0.5 * kPi : (k % 3 == 1 ? 0.0 : 0.5 * kPi);
+}
+
+// Tree._expansion (DecMCTS.py:201-231): one child per feasible primitive, in primitive order.
+__device__ inline void dm_expand(const uint32_t* d2, DmNode* T, int* n_nodes, int s, const DmParams& P,
+                                 unsigned long long* vis, double* cpose, int* cfeas, int tid) {
+    const int stage = T[s].stage;
+    if (stage >= P.horizon || T[s].nchild != 0) return;  // uniform: every lane reads the same node
+    if (tid < 9) {
+        double x = T[s].pose[0], y = T[s].pose[1], th = T[s].pose[2], v, w;
+        dm_prim(tid, v, w);
+        const bool ok = ig_next_pose(d2, x, y, th, v, w, P.xdt, P.dt, P.radius);
+        cfeas[tid] = ok ? 1 : 0;
+        cpose[3 * tid] = x; cpose[3 * tid + 1] = y; cpose[3 * tid + 2] = th;
+    }
+    __syncthreads();
+    const int first = *n_nodes;
+    int cnt = 0;
+    for (int k = 0; k < 9; k++) {
+        if (!cfeas[k] || first + cnt >= P.node_cap) continue;  // a full pool stops growing (sized so it never is)
+        const int c = first + cnt;
+        ig_visible_block(d2, cpose[3 * k], cpose[3 * k + 1], cpose[3 * k + 2], P.fov, P.range, vis, tid, DM_THREADS);
+        for (int j = tid; j < IG_BEL; j += DM_THREADS) {
+            T[c].observed[j] = T[s].observed[j] | vis[j];
+            T[c].best_obs[j] = 0ull;
+        }
+        if (tid == 0) {
+            T[c].mu = 0.0; T[c].Nv = 0.0; T[c].best = 0.0;
+            T[c].pose[0] = cpose[3 * k]; T[c].pose[1] = cpose[3 * k + 1]; T[c].pose[2] = cpose[3 * k + 2];
+            T[c].parent = s; T[c].child0 = -1;
+            T[c].nchild = 0; T[c].stage = (uint8_t)(stage + 1); T[c].has_roll = 0; T[c].seq_len = 0;
+            for (int a = 0; a < DM_MAXH; a++) { T[c].acts[a] = a < stage ? T[s].acts[a] : DM_NOACT; T[c].seq[a] = DM_NOACT; }
+            T[c].acts[stage] = (uint8_t)k;
+        }
+        cnt++;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        T[s].child0 = cnt ? first : -1;
+        T[s].nchild = (uint8_t)cnt;
+        *n_nodes = first + cnt;
+    }
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(DM_THREADS) k_dmcts_plan(IgDev G, DmParams P, const double* poses, DmNode* nodes,
+                                                         int32_t* n_nodes_all, DmPublished* pub_all, double* out_actions,
+                                                         uint8_t* out_paths, double* out_stats) {
+    __shared__ unsigned long long vis[IG_BEL], obs[IG_BEL], excl[IG_BEL], bobs[IG_BEL];
+    __shared__ double red[DM_THREADS];
+    __shared__ int redi[DM_THREADS];
+    __shared__ double cpose[27];
+    __shared__ int cfeas[9];
+    __shared__ double rew[DM_MAXSIMS];
+    __shared__ uint8_t tail[DM_MAXH], btail[DM_MAXH];
+    __shared__ int sh_sel, sh_pick, sh_n;
+    __shared__ int picks[DM_MAXCOMM];
+    __shared__ int dist_idx[DM_MAXR][DM_MAXCOMM];
+    __shared__ double dist_q[DM_MAXR][DM_MAXCOMM];
+    __shared__ int dist_n[DM_MAXR];
+    const int w = blockIdx.x, tid = threadIdx.x, R = P.R, H = P.horizon;
+    const uint32_t* d2 = G.d2 + (size_t)ig_scenario(G, w) * CAGYM_MAPD * CAGYM_MAPD;
+    const double* belief = G.belief + (size_t)w * IG_BEL * IG_BEL;
+    DmPublished* pub = pub_all + (size_t)w * R;
+
+    // ---- Tree.__init__ (DecMCTS.py:92-138): root + expansion of the root; my_act_dist = the root state alone -----
+    for (int r = 0; r < R; r++) {
+        DmNode* T = nodes + ((size_t)w * R + r) * P.node_cap;
+        int* nn = n_nodes_all + (size_t)w * R + r;
+        for (int j = tid; j < IG_BEL; j += DM_THREADS) { T[0].observed[j] = 0ull; T[0].best_obs[j] = 0ull; }
+        if (tid == 0) {
+            T[0].mu = 0.0; T[0].Nv = 0.0; T[0].best = 0.0;
+            T[0].pose[0] = poses[((size_t)w * R + r) * 3]; T[0].pose[1] = poses[((size_t)w * R + r) * 3 + 1];
+            T[0].pose[2] = poses[((size_t)w * R + r) * 3 + 2];
+            T[0].parent = -1; T[0].child0 = -1; T[0].nchild = 0; T[0].stage = 0; T[0].has_roll = 0; T[0].seq_len = 0;
+            for (int a = 0; a < DM_MAXH; a++) { T[0].acts[a] = DM_NOACT; T[0].seq[a] = DM_NOACT; }
+            *nn = 1;
+            dist_n[r] = 1; dist_idx[r][0] = 0; dist_q[r][0] = 1.0;
+        }
+        __syncthreads();
+        dm_expand(d2, T, nn, 0, P, vis, cpose, cfeas, tid);
+    }
+
+    for (int cycle = 0; cycle < P.Ncycles; cycle++) {
+        for (int r = 0; r < R; r++) {
+            DmNode* T = nodes + ((size_t)w * R + r) * P.node_cap;
+            int* nn = n_nodes_all + (size_t)w * R + r;
+            for (int g = 0; g < P.Ntree; g++) {
+                const unsigned int call = P.call_base + (unsigned int)((cycle * R + r) * P.Ntree + g) + 1u;
+                // ---- _get_system_state (DecMCTS.py:182-194): one sampled plan per robot this one listens to -------
+                for (int j = tid; j < IG_BEL; j += DM_THREADS) excl[j] = 0ull;
+                __syncthreads();
+                for (int other = 0; other < R - 1; other++) {  // Q15 listening graph (see dmcts.py)
+                    if (other == r || pub[other].n <= 0) continue;  // uniform
+                    if (tid == 0) {
+                        const int n = pub[other].n;
+                        double tot = 0.0;
+                        for (int k = 0; k < n; k++) tot += pub[other].q[k];
+                        const double thr = dm_u01(P.seed ^ 0x5DEECE66Dull, (unsigned int)w, (call << 4) | (unsigned int)other) * tot;
+                        int pick = n - 1;
+                        double run = 0.0;
+                        for (int k = 0; k < n; k++) {
+                            run += pub[other].q[k];
+                            if (run > thr) { pick = k; break; }
+                        }
+                        sh_pick = pick;
+                    }
+                    __syncthreads();
+                    for (int j = tid; j < IG_BEL; j += DM_THREADS) excl[j] |= pub[other].obs[sh_pick][j];
+                    __syncthreads();
+                }
+                // ---- selection (DecMCTS.py:14-18, 140-153, 288-289) --------------------------------------------------
+                if (tid == 0) {
+                    int node = 0;
+                    while (T[node].nchild > 0) {
+                        const double n_p = T[node].Nv;
+                        int bi = -1;
+                        double bu = -INFINITY;
+                        for (int k = 0; k < T[node].nchild; k++) {
+                            const DmNode& ch = T[T[node].child0 + k];
+                            double u;
+                            if (ch.Nv == 0.0) u = INFINITY;
+                            else u = n_p > 0.0 ? ch.mu + 2 * P.c_p * sqrt(2 * log(n_p) / ch.Nv) : ch.mu;
+                            if (u > bu) { bu = u; bi = T[node].child0 + k; }
+                        }
+                        node = bi;
+                    }
+                    sh_sel = node;
+                }
+                __syncthreads();
+                const int s = sh_sel;
+                dm_expand(d2, T, nn, s, P, vis, cpose, cfeas, tid);
+                // ---- simulation (DecMCTS.py:233-271, 296-327): Nsims random roll-outs from the selected node ----------
+                const int steps = H - T[s].stage;
+                const unsigned long long rseed = P.seed * 1000003ull + (unsigned long long)call;
+                double best = -INFINITY;
+                for (int sim = 0; sim < P.Nsims; sim++) {
+                    for (int j = tid; j < IG_BEL; j += DM_THREADS) obs[j] = T[s].observed[j];
+                    __syncthreads();
+                    double x = T[s].pose[0], y = T[s].pose[1], th = T[s].pose[2];
+                    for (int t = 0; t < steps; t++) {
+                        const uint32_t k = ig_rand_primitive(rseed, (uint32_t)w, (uint32_t)sim, (uint32_t)t);
+                        double v, wv;
+                        dm_prim((int)k, v, wv);
+                        const bool ok = ig_next_pose(d2, x, y, th, v, wv, P.xdt, P.dt, P.radius);  // uniform
+                        if (ok) {
+                            ig_visible_block(d2, x, y, th, P.fov, P.range, vis, tid, DM_THREADS);
+                            for (int j = tid; j < IG_BEL; j += DM_THREADS) obs[j] |= vis[j];
+                            __syncthreads();
+                        }
+                        if (tid == 0) tail[t] = ok ? (uint8_t)k : (uint8_t)DM_INFEAS;
+                    }
+                    for (int j = tid; j < IG_BEL; j += DM_THREADS) vis[j] = obs[j] & ~excl[j];  // mcts_reward (ig_mcts.py:234-241)
+                    __syncthreads();
+                    const double rr = ig_reward_block(belief, vis, red, tid, DM_THREADS);
+                    if (tid == 0) rew[sim] = rr;
+                    if (rr > best) {  // uniform; `if rew > best_reward` keeps the first maximum
+                        best = rr;
+                        for (int j = tid; j < IG_BEL; j += DM_THREADS) bobs[j] = obs[j];
+                        if (tid == 0)
+                            for (int t = 0; t < DM_MAXH; t++) btail[t] = t < steps ? tail[t] : (uint8_t)DM_NOACT;
+                    }
+                    __syncthreads();
+                }
+                // ---- back-propagation (DecMCTS.py:329-356) ----------------------------------------------------------------
+                for (int j = tid; j < IG_BEL; j += DM_THREADS) T[s].best_obs[j] = bobs[j];
+                if (tid == 0) {
+                    double acc = 0.0;
+                    for (int sim = 0; sim < P.Nsims; sim++) acc += rew[sim];
+                    const double avg = acc / P.Nsims;
+                    const int st = T[s].stage;
+                    T[s].mu = avg; T[s].best = best; T[s].Nv = 1.0; T[s].has_roll = 1;
+                    T[s].seq_len = (uint8_t)H;
+                    for (int a = 0; a < DM_MAXH; a++) T[s].seq[a] = a < st ? T[s].acts[a] : (a < H ? btail[a - st] : (uint8_t)DM_NOACT);
+                    red[0] = avg;
+                }
+                __syncthreads();
+                const double avg = red[0];
+                __syncthreads();
+                for (int a = T[s].parent; a >= 0; a = T[a].parent) {  // uniform walk
+                    const bool better = best > T[a].best;
+                    __syncthreads();
+                    if (better)
+                        for (int j = tid; j < IG_BEL; j += DM_THREADS) T[a].best_obs[j] = bobs[j];
+                    if (tid == 0) {
+                        T[a].mu = (P.gamma * T[a].mu * T[a].Nv + avg) / (T[a].Nv + 1);
+                        T[a].Nv = P.gamma * T[a].Nv + 1;
+                        if (better) {
+                            T[a].best = best;
+                            T[a].has_roll = 1;
+                            T[a].seq_len = T[s].seq_len;
+                            for (int q = 0; q < DM_MAXH; q++) T[a].seq[q] = T[s].seq[q];
+                        }
+                    }
+                    __syncthreads();
+                }
+                // ---- _update_distribution (DecMCTS.py:162-180): top comm_n nodes by mu (first created first on ties),
+                //      those with a roll-out, q = mu^2 -------------------------------------------------------------------------
+                const int total = *nn;
+                for (int round = 0; round < P.comm_n; round++) {
+                    double bm = -INFINITY;
+                    int bi = 0x7fffffff;
+                    for (int i = 1 + tid; i < total; i += DM_THREADS) {
+                        bool taken = false;
+                        for (int q = 0; q < round; q++) taken |= picks[q] == i;
+                        if (taken) continue;
+                        const double m = T[i].mu;
+                        if (m > bm || (m == bm && i < bi)) { bm = m; bi = i; }
+                    }
+                    red[tid] = bm;
+                    redi[tid] = bi;
+                    __syncthreads();
+                    for (int step = DM_THREADS / 2; step > 0; step >>= 1) {  // arg-max over (mu desc, index asc)
+                        if (tid < step) {
+                            const double m2 = red[tid + step];
+                            const int i2 = redi[tid + step];
+                            if (m2 > red[tid] || (m2 == red[tid] && i2 < redi[tid])) { red[tid] = m2; redi[tid] = i2; }
+                        }
+                        __syncthreads();
+                    }
+                    if (tid == 0) picks[round] = redi[0];
+                    __syncthreads();
+                }
+                if (tid == 0) {
+                    int cnt = 0;
+                    int keep[DM_MAXCOMM];
+                    for (int q = 0; q < P.comm_n; q++)
+                        if (picks[q] != 0x7fffffff && T[picks[q]].has_roll) keep[cnt++] = picks[q];
+                    sh_n = cnt;
+                    for (int q = 0; q < cnt; q++) dist_idx[r][q] = keep[q];  // an empty list leaves the distribution as it was
+                }
+                __syncthreads();
+                if (tid == 0 && sh_n > 0) {
+                    double tot = 0.0;
+                    for (int q = 0; q < sh_n; q++) tot += T[dist_idx[r][q]].mu * T[dist_idx[r][q]].mu;
+                    for (int q = 0; q < sh_n; q++)
+                        dist_q[r][q] = tot == 0.0 ? 1.0 / sh_n : T[dist_idx[r][q]].mu * T[dist_idx[r][q]].mu / tot;
+                    dist_n[r] = sh_n;
+                }
+                __syncthreads();
+            }
+            // ---- send_comms: publish this robot's distribution (ig_mcts.py:107) ------------------------------------------
+            const int n = dist_n[r];
+            for (int q = 0; q < n; q++) {
+                const DmNode& src = T[dist_idx[r][q]];
+                // the root entry of a tree without roll-outs has no best roll-out: it stands for "stay", nothing observed
+                for (int j = tid; j < IG_BEL; j += DM_THREADS) pub[r].obs[q][j] = src.has_roll ? src.best_obs[j] : src.observed[j];
+            }
+            if (tid == 0) {
+                pub[r].n = n;
+                for (int q = 0; q < n; q++) pub[r].q[q] = dist_q[r][q];
+                const DmNode& b = T[dist_idx[r][0]];
+                pub[r].seq_len = b.has_roll ? b.seq_len : 0;
+                for (int a = 0; a < DM_MAXH; a++) pub[r].seq0[a] = b.has_roll ? b.seq[a] : (uint8_t)DM_NOACT;
+            }
+            __syncthreads();
+        }
+    }
+    // ---- action = first action of the best path (ig_mcts.py:109) --------------------------------------------------------
+    if (tid < R) {
+        const int r = tid;
+        const DmPublished& p = pub[r];
+        double v = 0.0, wv = 0.0;
+        if (p.seq_len > 0 && p.seq0[0] < 9) dm_prim(p.seq0[0], v, wv);
+        out_actions[((size_t)w * R + r) * 2] = v;
+        out_actions[((size_t)w * R + r) * 2 + 1] = wv;
+        for (int a = 0; a < DM_MAXH; a++) out_paths[((size_t)w * R + r) * DM_MAXH + a] = a < p.seq_len ? p.seq0[a] : (uint8_t)DM_NOACT;
+        const DmNode* T = nodes + ((size_t)w * R + r) * P.node_cap;
+        out_stats[((size_t)w * R + r) * 3] = T[0].mu;
+        out_stats[((size_t)w * R + r) * 3 + 1] = T[0].Nv;
+        out_stats[((size_t)w * R + r) * 3 + 2] = (double)n_nodes_all[(size_t)w * R + r];
+    }
+}

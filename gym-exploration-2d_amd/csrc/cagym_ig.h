@@ -3,7 +3,7 @@
 //
 // Replaces information_models/edfMap.py, information_models/targetMap.py and the planner primitives of
 // policies/ig_mcts.py:154-253 + pydecmcts/DecMCTS.py:233-271 (reference paths under
-// gym_collision_avoidance/envs/).  The networkx tree bookkeeping stays on the host.
+// gym_collision_avoidance/envs/).  The tree itself: cagym_dmcts.h (device) or dmcts.py (host).
 //
 // Memory: per scenario a 300x300 u32 field of SQUARED cell distances (360 KB, L2/MALL resident;
 // EDF = sqrt(d2) * 0.1 exactly as scipy's exact EDT), per world a 60x60 fp64 belief grid of odds ratios.

@@ -232,3 +232,55 @@ class DecMCTSPlanner(object):
                 if seq and seq[0] >= 0:
                     actions[w, r] = PRIMITIVES[seq[0]]
         return actions, paths
+
+
+class DeviceDecMCTSPlanner(object):
+    """Same planner with the trees on the device (cagym_dmcts_plan, csrc/cagym_dmcts.h): one workgroup per world grows
+    the trees of all its robots; nothing but the poses goes in and the chosen actions come out.  Makes the same
+    decisions as DecMCTSPlanner(InfoGainBackend(ig), ...) for the same seed."""
+
+    def __init__(self, ig, n_robots, radius=0.5, Ntree=30, Nsims=10, horizon=4, c_p=1.0, gamma=0.95, Ncycles=5, comm_n=5,
+                 seed=0):
+        import ctypes as C
+        import torch
+        from . import _lib
+        self._C, self._torch, self._lib = C, torch, _lib
+        self.ig, self.b, self.L = ig, ig.b, ig.L
+        self.N, self.R = ig.b.N, int(n_robots)
+
+        class Params(C.Structure):
+            _fields_ = [(n, C.c_int32) for n in ("n_robots", "Ntree", "Nsims", "horizon", "Ncycles", "comm_n", "xdt",
+                                                 "reset_comms")] + [("call_base", C.c_uint32), ("pad", C.c_uint32)] + \
+                       [(n, C.c_double) for n in ("c_p", "gamma", "radius", "dt", "fov_rad", "range")] + [("seed", C.c_uint64)]
+        self.P = Params(self.R, int(Ntree), int(Nsims), int(horizon), int(Ncycles), int(comm_n), ig.xdt, 1, 0, 0,
+                        float(c_p), float(gamma), float(radius), ig.dt, ig.fov, ig.range, int(seed) & _M64)
+        self.L.cagym_dmcts_workspace_bytes.restype = C.c_size_t
+        self.L.cagym_dmcts_workspace_bytes.argtypes = [C.c_int, C.POINTER(Params)]
+        self.L.cagym_dmcts_plan.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
+                                            C.c_void_p, C.c_void_p, C.c_void_p]
+        nbytes = self.L.cagym_dmcts_workspace_bytes(self.N, C.byref(self.P))
+        dev = self.b.device
+        self.workspace = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+        self.actions = torch.zeros((self.N, self.R, 2), dtype=torch.float64, device=dev)
+        self.paths = torch.zeros((self.N, self.R, 8), dtype=torch.uint8, device=dev)
+        self.stats = torch.zeros((self.N, self.R, 3), dtype=torch.float64, device=dev)
+        self.calls = 0
+
+    def reset(self):
+        """Forget the communicated plans at the next plan() (new episode)."""
+        self.P.reset_comms = 1
+
+    def plan(self, poses):
+        """poses [N, R, 3] (torch or numpy).  Returns device tensors (actions [N,R,2], paths [N,R,8] uint8, where
+        254 marks an infeasible random draw and 255 the end of the path)."""
+        torch, C = self._torch, self._C
+        p = torch.as_tensor(poses, device=self.b.device).to(torch.float64).reshape(self.N, self.R, 3).contiguous()
+        self.P.call_base = self.calls & 0xFFFFFFFF
+        with torch.cuda.device(self.b.device):
+            rc = self.L.cagym_dmcts_plan(self.b.h, C.byref(self.P), p.data_ptr(), self.workspace.data_ptr(),
+                                         self.workspace.numel(), self.actions.data_ptr(), self.paths.data_ptr(),
+                                         self.stats.data_ptr(), self.b._stream())
+        self._lib.check(self.L, self.b.h, rc, "cagym_dmcts_plan")
+        self.calls += self.R * self.P.Ncycles * self.P.Ntree
+        self.P.reset_comms = 0
+        return self.actions, self.paths

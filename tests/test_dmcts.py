@@ -151,3 +151,50 @@ def test_gpu_backend_plans_like_oracle_backend():
         for w in range(N):
             assert len(pg.trees[r][w].nodes) == len(pc.trees[r][w].nodes)
             assert abs(pg.trees[r][w].root.mu - pc.trees[r][w].root.mu) < 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("budget", [dict(Ntree=8, Nsims=5, Ncycles=3), dict(Ntree=30, Nsims=10, Ncycles=5)])
+def test_device_tree_decides_like_the_host_tree(budget):
+    """cagym_dmcts_plan (trees on the device) against DecMCTSPlanner (host tree, same device primitives): identical
+    best paths, actions and root statistics over two consecutive planning steps (the second one hears the plans
+    communicated in the first)."""
+    import torch
+    B = importlib.import_module("gym-exploration-2d_amd.batched_env").BatchedCollisionAvoidanceEnv
+    igm = importlib.import_module("gym-exploration-2d_amd.ig")
+    N, M = 6, 4
+    env = B(N, M, max_obstacles=4, game_over_mode="all")
+    env.set_scenarios(scen.random_worlds_fast(N, M, seed=2), scen.POLICY_STATIC, scen.DYN_FIRSTORDER,
+                      obstacles=np.tile(np.array(OBST, dtype=np.float64)[None], (N, 1, 1)), n_obst=[4] * N)
+    env.reset()
+    ig = igm.InfoGain(env)
+    rng = np.random.default_rng(5)
+    base = np.array([[-5, 0, 0], [0, 0, 0], [5, 0, 0]], dtype=np.float64)
+    poses = np.stack([base + np.concatenate([rng.uniform(-0.8, 0.8, (3, 2)), rng.uniform(-3, 3, (3, 1))], 1) for _ in range(N)])
+    poses[0] = base
+    kw = dict(radius=0.5, horizon=4, c_p=1.0, gamma=0.95, seed=21, **budget)  # second budget: experiments/src/dmcts.py:31-36
+    host = dm.DecMCTSPlanner(igm.InfoGainBackend(ig), N, 3, **kw)
+    dev = dm.DeviceDecMCTSPlanner(ig, 3, **kw)
+    for step in range(2):
+        ah, ph = host.plan(poses)
+        ad, pd = dev.plan(poses)
+        torch.cuda.synchronize()
+        ad, pd, st = ad.cpu().numpy(), pd.cpu().numpy(), dev.stats.cpu().numpy()
+        for w in range(N):
+            for r in range(3):
+                seq = [254 if a < 0 else a for a in ph[w][r]]
+                assert list(pd[w, r, :len(seq)]) == seq and (pd[w, r, len(seq):] == 255).all(), (step, w, r, seq, pd[w, r])
+                t = host.trees[r][w]
+                assert int(st[w, r, 2]) == len(t.nodes)
+                assert abs(st[w, r, 0] - t.root.mu) <= 1e-12 * max(1.0, abs(t.root.mu)) and abs(st[w, r, 1] - t.root.N) < 1e-12
+        assert np.array_equal(ad, ah)
+        poses = poses + np.array([0.3, 0.1, 0.2])  # the robots moved; the next step hears this step's plans
+    assert host.calls == dev.calls
+    # a pose inside an obstacle: no feasible primitive moves, the planner answers (0, 0) or a turn in place
+    bad = poses.copy()
+    bad[:, 0, :2] = [6.0, 6.0]
+    dev.reset()
+    a, p = dev.plan(bad)
+    torch.cuda.synchronize()
+    assert (a[:, 0, 0].cpu().numpy() == 0.0).all()
+    env.close()

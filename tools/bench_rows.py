@@ -130,5 +130,17 @@ planner.plan(pp)
 dtp = time.perf_counter() - t0
 out["dmcts_plan_64_worlds_3_robots_s"] = dtp
 out["dmcts_rollouts_per_s_incl_host_tree"] = NW * 3 * 5 * 30 * 10 / dtp
+# the same planning step with the trees on the device, for ALL 2048 worlds
+dplanner = dm.DeviceDecMCTSPlanner(ig, 3, radius=0.5, Ntree=30, Nsims=10, horizon=4, Ncycles=5, seed=1)
+pp_all = torch.from_numpy(np.concatenate([a6[:, :3, 0:2], np.zeros((N, 3, 1))], axis=2)).to(env.device)
+dplanner.plan(pp_all)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+dplanner.plan(pp_all)
+torch.cuda.synchronize()
+dtd = time.perf_counter() - t0
+out["dmcts_device_plan_2048_worlds_3_robots_s"] = dtd
+out["dmcts_device_rollouts_per_s"] = N * 3 * 5 * 30 * 10 / dtd
+out["dmcts_device_workspace_GB"] = dplanner.workspace.numel() / 1e9
 env.close()
 print(json.dumps(out, indent=1))
