@@ -162,7 +162,7 @@ def main():
         balg = B_ALG[args.policy]
         # the library's own rule (cagym_api.hip): M = 10 runs 4 worlds per workgroup while the launch is co-resident
         cus = torch.cuda.get_device_properties(device).multi_processor_count
-        spec = {10: "256, 10, %d" % (4 if (N + 3) // 4 <= 5 * cus else 5), 4: "256, 4, 0", 20: "512, 20, 2"}
+        spec = {10: "256, 10, %d" % (4 if (N + 3) // 4 <= 5 * cus else 5), 4: "256, 4, 0", 20: "256, 20, 2"}
         kernel_name = "%s<%s, true>" % ("k_step2" if args.per_step_launch else "k_rollout2",
                                         spec.get(M, "256, 0, 0" if M <= 12 else "512, 0, 0"))
         achieved = balg * N * M * steps_per_launch / (launch_ms * 1e-3) / 1e9

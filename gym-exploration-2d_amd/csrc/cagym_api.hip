@@ -79,8 +79,13 @@ CagymOut to_out(const cagym_outputs* o) {
 //   M = 10:  5 worlds (225 unordered / 500 directed pair slots, ~35 live agents = 2 rounds of 32 LP groups), or
 //            4 worlds while every workgroup of the launch is co-resident (<= 5 per CU): ~28 live agents = one
 //            round of LP groups; measured 4096 worlds: 259 vs 247 M env-steps/s, 65536 worlds: 342 vs 392
-//   M = 20:  2 worlds, 380 unordered / 800 directed pair slots on 512 lanes
+//   M = 20:  2 worlds, 380 unordered / 800 directed pair slots on 256 lanes (5 workgroups per CU instead of 2)
+#ifndef WPW20
 #define WPW20 2
+#endif
+#ifndef NT20
+#define NT20 256  /* lanes per workgroup of the M = 20 specialisation (512: 64 vs 78 M env-steps/s at 2048 x 20) */
+#endif
 inline int wpw_spec(const Env* e) {
     const int M = e->cfg.max_agents;
     return M == 10 ? e->wpw10 : (M == 20 ? WPW20 : 0);
@@ -182,11 +187,11 @@ int cagym_create(const cagym_config* cfg, void** env_out) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<256, 10, 5, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<256, 10, 4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<256, 4, 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<512, 20, WPW20, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<NT20, 20, WPW20, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<256, 4, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<256, 4, 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<512, 20, WPW20, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<512, 20, WPW20, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<NT20, 20, WPW20, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<NT20, 20, WPW20, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<256, 10, 5, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<256, 10, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<256, 10, 5, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
@@ -196,7 +201,7 @@ int cagym_create(const cagym_config* cfg, void** env_out) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<256, 10, 5, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<256, 10, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<256, 4, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<512, 20, WPW20, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<NT20, 20, WPW20, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<512, 0, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<512, 0, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<512, 0, 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
@@ -360,7 +365,7 @@ int cagym_step(void* env, const float* ext_actions, const cagym_outputs* out, vo
         if (M == 10 && e->wpw10 == 4) hipLaunchKernelGGL((k_step2<256, 10, 4, false>), dim3(n_wg2(e)), dim3(256), lds2, st, e->D, ext_actions, o, e->any_rvo);
         else if (M == 10) hipLaunchKernelGGL((k_step2<256, 10, 5, false>), dim3(n_wg2(e)), dim3(256), lds2, st, e->D, ext_actions, o, e->any_rvo);
         else if (M == 4) hipLaunchKernelGGL((k_step2<256, 4, 0, false>), dim3(n_wg2(e)), dim3(256), lds2, st, e->D, ext_actions, o, e->any_rvo);
-        else if (M == 20) hipLaunchKernelGGL((k_step2<512, 20, WPW20, false>), dim3(n_wg2(e)), dim3(512), lds2, st, e->D, ext_actions, o, e->any_rvo);
+        else if (M == 20) hipLaunchKernelGGL((k_step2<NT20, 20, WPW20, false>), dim3(n_wg2(e)), dim3(NT20), lds2, st, e->D, ext_actions, o, e->any_rvo);
         else if (M <= 12) hipLaunchKernelGGL((k_step2<256, 0, 0, false>), dim3(n_waves(e)), dim3(256), lds2, st, e->D, ext_actions, o, e->any_rvo);
         else if (M <= 16) hipLaunchKernelGGL((k_step2<512, 0, 0, false>), dim3(n_waves(e)), dim3(512), lds2, st, e->D, ext_actions, o, e->any_rvo);
         else hipLaunchKernelGGL((k_step2<512, 0, 0, false>), dim3(n_waves(e)), dim3(512), lds2, st, e->D, ext_actions, o, e->any_rvo);
@@ -383,7 +388,7 @@ int cagym_step_autoreset(void* env, const float* ext_actions, const cagym_output
         if (M == 10 && e->wpw10 == 4) hipLaunchKernelGGL((k_step2<256, 10, 4, true>), dim3(n_wg2(e)), dim3(256), lds2, st, e->D, ext_actions, o, e->any_rvo);
         else if (M == 10) hipLaunchKernelGGL((k_step2<256, 10, 5, true>), dim3(n_wg2(e)), dim3(256), lds2, st, e->D, ext_actions, o, e->any_rvo);
         else if (M == 4) hipLaunchKernelGGL((k_step2<256, 4, 0, true>), dim3(n_wg2(e)), dim3(256), lds2, st, e->D, ext_actions, o, e->any_rvo);
-        else if (M == 20) hipLaunchKernelGGL((k_step2<512, 20, WPW20, true>), dim3(n_wg2(e)), dim3(512), lds2, st, e->D, ext_actions, o, e->any_rvo);
+        else if (M == 20) hipLaunchKernelGGL((k_step2<NT20, 20, WPW20, true>), dim3(n_wg2(e)), dim3(NT20), lds2, st, e->D, ext_actions, o, e->any_rvo);
         else if (M <= 12) hipLaunchKernelGGL((k_step2<256, 0, 0, true>), dim3(n_waves(e)), dim3(256), lds2, st, e->D, ext_actions, o, e->any_rvo);
         else if (M <= 16) hipLaunchKernelGGL((k_step2<512, 0, 0, true>), dim3(n_waves(e)), dim3(512), lds2, st, e->D, ext_actions, o, e->any_rvo);
         else hipLaunchKernelGGL((k_step2<512, 0, 0, true>), dim3(n_waves(e)), dim3(512), lds2, st, e->D, ext_actions, o, e->any_rvo);
@@ -416,7 +421,7 @@ int cagym_rollout(void* env, int n_steps, int auto_reset, const cagym_outputs* o
         if (M == 10 && e->wpw10 == 4) ROLL2(256, 10, 4);
         else if (M == 10) ROLL2(256, 10, 5);
         else if (M == 4) ROLL2(256, 4, 0);
-        else if (M == 20) ROLL2(512, 20, WPW20);
+        else if (M == 20) ROLL2(NT20, 20, WPW20);
         else if (M <= 12) ROLL2(256, 0, 0);
         else ROLL2(512, 0, 0);
 #undef ROLL2
