@@ -537,12 +537,17 @@ __device__ inline void orca_lp_group(const float4* L, float4* P, int a, int j, i
         }
         cur = i + 1;
     }
-    // linearProgram3
+    // linearProgram3 (rare).  Same scan-and-jump: the next line at or after `cur` that is violated by more than
+    // `distance`, then linearProgram2 (directionOpt) over the projected lines, again by scan-and-jump.
     float distance = 0.0f;
-#pragma nounroll
-    for (int i = fail; i < nn; i++) {  // rare: lines re-read from LDS, loop kept rolled
+    for (int cur = fail; cur < nn;) {
+        const bool w1 = j >= cur && j < nn && detf(lj.z, lj.w, lj.x - rx, lj.y - ry) > distance;
+        const bool w2 = extra && GW >= cur && detf(lx.z, lx.w, lx.x - rx, lx.y - ry) > distance;
+        const uint32_t wm = (uint32_t)((__ballot(w1) >> gbase) & gbits) | ((uint32_t)((__ballot(w2) >> gbase) & 1ull) << GW);
+        if (!wm) break;
+        const int i = __ffs((int)wm) - 1;
+        cur = i + 1;
         const float4 li = L[i * stride + a];
-        if (!(detf(li.z, li.w, li.x - rx, li.y - ry) > distance)) continue;
         // projected line of lane j (j < i); `have` = it exists (not "parallel, same direction")
         bool have = false;
         float4 pj = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -564,15 +569,17 @@ __device__ inline void orca_lp_group(const float4* L, float4* P, int a, int j, i
             pj.w = ddy * inv;
             if (have) P[j] = pj;
         }
-        const uint32_t hmask = (uint32_t)((__ballot(have) >> gbase) & ((1ull << GW) - 1ull));
         const float px = -li.w, py = li.z;
         const float tx = rx, ty = ry;
         float qx = px * radius, qy = py * radius;  // linearProgram2, directionOpt
         bool failed = false;
-        for (int k = 0; k < i; k++) {
-            if (!((hmask >> k) & 1u)) continue;
-            const float4 pk = P[k];
-            if (!(detf(pk.z, pk.w, pk.x - qx, pk.y - qy) > 0.0f)) continue;
+        for (int kcur = 0; kcur < i;) {
+            const bool u = have && j >= kcur && detf(pj.z, pj.w, pj.x - qx, pj.y - qy) > 0.0f;
+            const uint32_t um = (uint32_t)((__ballot(u) >> gbase) & gbits);
+            if (!um) break;
+            const int k = __ffs((int)um) - 1;
+            kcur = k + 1;
+            const float4 pk = P[k];  // lane k's projected line (same wave: the LDS write above is ordered before this read)
             if (!orca_lp1_group<GW>(pk, pj, j < k && have, radius, px, py, true, gbase, qx, qy)) {
                 failed = true;
                 break;
