@@ -201,6 +201,16 @@ __device__ __forceinline__ void publish_rvo_list(const Lds2& W, int tid, bool is
     if (tid == 0) W.lpmask[0] = (unsigned long long)__popcll(m);
 }
 
+// prefVelocity = pref_speed (goal - pos) / |goal - pos| and maxSpeed of agent a (RVOPolicy.py:65-85, as orca_ego),
+// from the agent record in LDS into the slots the next LP phase reads (lpv doubles as the LP result afterwards).
+__device__ __forceinline__ void publish_pref_velocity(const Lds2& W, int a) {
+    const double gx = W.tgx[a] - W.tpx[a], gy = W.tgy[a] - W.tpy[a];
+    const double pref = W.tpref[a];
+    const double sc = pref / norm2(gx, gy);
+    W.lpv[a] = make_float2((float)(sc * gx), (float)(sc * gy));
+    W.lpr[a] = (float)pref;
+}
+
 // One env.step() of the workgroup's worlds.  Agent registers A live on wave 0 (tid < 64) only; the pair
 // phases keep nothing in registers across barriers (everything is re-read from LDS).
 template <int NT, int MT, int WPWT, bool AUTO_RESET>
@@ -313,14 +323,14 @@ __device__ inline void step_core2(const CagymDev& D, const Lds2& W, LaneCtx& C, 
                         if (rank < CAGYM_MAXNB) W.sorted[rank * AS + a] = W.lines[a * MP + sl];
                     }
                 }
-                // prefVelocity and maxSpeed of the ego (RVOPolicy.py:65-85), as orca_ego
-                const double gx = W.tgx[a] - W.tpx[a], gy = W.tgy[a] - W.tpy[a];
-                const double pref = W.tpref[a];
-                const double sc = pref / norm2(gx, gy);
+                // prefVelocity and maxSpeed of the ego were published by publish_pref_velocity (idle lanes of the
+                // previous step's last phase, or the kernel prologue)
+                const float2 pv = W.lpv[a];
+                const float rad = W.lpr[a];
                 float vx, vy;
-                STAMP(10);  // list read + ego set-up
+                STAMP(10);  // list read + ranking
                 // linearProgram3 scratch: the ego's own (now dead) row of unsorted half-planes, MP >= nn entries
-                orca_lp_group<GW>(W.sorted, W.lines + a * MP, a, j, nn, (float)pref, (float)(sc * gx), (float)(sc * gy), vx, vy, AS);
+                orca_lp_group<GW>(W.sorted, W.lines + a * MP, a, j, nn, rad, pv.x, pv.y, vx, vy, AS);
                 if (j == 0) W.lpv[a] = make_float2(vx, vy);
                 STAMP(11);  // LP of group 0's agent
             }
@@ -572,6 +582,8 @@ __device__ inline void step_core2(const CagymDev& D, const Lds2& W, LaneCtx& C, 
 #pragma unroll
         for (int c = 0; c < 5; c++) r2[c] = make_float2(v[2 * c], v[2 * c + 1]);
     }
+    // the last wave is idle in the second round of the row loop: it prepares the next step's LP inputs
+    if (any_rvo && tid >= NT - CAGYM_WAVE && tid - (NT - CAGYM_WAVE) < C.wpw * M) publish_pref_velocity(W, tid - (NT - CAGYM_WAVE));
     STAMP(6);
     // ---- ego observation from the agent lanes ---------------------------------------------------------
     if (agent_lane && C.valid) {
@@ -613,6 +625,7 @@ __global__ void __launch_bounds__(NT, (NT <= 256 ? 3 : 2)) k_rollout2(CagymDev D
         lds_store_agent(W, A, threadIdx.x);
         if (C.wl < C.wpw && C.slot == 0) W.wn[C.wl] = C.valid ? C.n : 0;
         publish_rvo_list(W, threadIdx.x, C.valid && C.active && !(A.st & CAGYM_FLAG_DONE) && ST_POLICY(A.st) == CAGYM_POL_RVO);
+        publish_pref_velocity(W, threadIdx.x);
     }
     const size_t NM = (size_t)D.N * M;
 #pragma nounroll
@@ -658,6 +671,7 @@ __global__ void __launch_bounds__(NT) k_step2(CagymDev D, const float* ext, Cagy
         lds_store_agent(W, A, threadIdx.x);
         if (C.wl < C.wpw && C.slot == 0) W.wn[C.wl] = C.valid ? C.n : 0;
         publish_rvo_list(W, threadIdx.x, C.valid && C.active && !(A.st & CAGYM_FLAG_DONE) && ST_POLICY(A.st) == CAGYM_POL_RVO);
+        publish_pref_velocity(W, threadIdx.x);
     }
     step_core2<NT, MT, WPWT, AUTO_RESET>(D, W, C, ext, out, ep_ret, ep_len, any_rvo != 0);
     if (C.valid) {
