@@ -171,7 +171,10 @@ __device__ __forceinline__ double carrl_heading(int k) {
 }
 
 // Agent.take_action (agent.py:147-190) + dynamics/*.py.  `act` is the fp32 pair of env.py:289.
-__device__ __forceinline__ void take_action(Agent& A, float act0, float act1, double dt) {
+// Returns whether the agent moved (false: it was already done).  EGO = false leaves Dynamics.update_ego_frame to the
+// caller (the phase-split kernels run it on otherwise idle lanes of the next pair phase; nothing below reads it).
+template <bool EGO = true>
+__device__ __forceinline__ bool take_action(Agent& A, float act0, float act1, double dt) {
     A.a0 = act0;  // all_actions row (env.py:289): zeros for an agent that is already done
     A.a1 = act1;
     if (A.st & (CAGYM_FLAG_AT_GOAL | CAGYM_FLAG_RAN_OUT_OF_TIME | CAGYM_FLAG_IN_COLLISION)) {  // agent.py:148-159
@@ -179,7 +182,7 @@ __device__ __forceinline__ void take_action(Agent& A, float act0, float act1, do
         if (A.st & CAGYM_FLAG_IN_COLLISION) A.st |= CAGYM_FLAG_WAS_IN_COLLISION;
         if (!(A.st & CAGYM_FLAG_AT_GOAL)) A.t += dt;
         A.vx = A.vy = 0.0;
-        return;
+        return false;
     }
     double a0 = (double)act0, a1 = (double)act1;
     double h = A.h, speed, hn;
@@ -228,8 +231,10 @@ __device__ __forceinline__ void take_action(Agent& A, float act0, float act1, do
     A.speed = speed;
     A.dh = wrap_angle(hn - h);
     A.h = hn;
-    double prx, pry;
-    update_ego_frame(A, prx, pry);
+    if (EGO) {
+        double prx, pry;
+        update_ego_frame(A, prx, pry);
+    }
     double ex = A.px - A.gx, ey = A.py - A.gy;
     if (ex * ex + ey * ey <= 0.75 * 0.75) A.st |= CAGYM_FLAG_AT_GOAL;  // utils/end_conditions.py:3-6
     else A.st &= ~(uint32_t)CAGYM_FLAG_AT_GOAL;
@@ -237,6 +242,7 @@ __device__ __forceinline__ void take_action(Agent& A, float act0, float act1, do
     A.t += dt;
     A.step += 1;
     if (A.trem <= 0.0) A.st |= CAGYM_FLAG_RAN_OUT_OF_TIME;
+    return true;
 }
 
 // Map.world_coordinates_to_map_indices (Map.py:40-47)

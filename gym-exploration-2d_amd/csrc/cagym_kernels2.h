@@ -44,6 +44,7 @@ struct Lds2 {
     float* tcoop;
     uint32_t* tst;
     int* tstep;
+    int* tmoved;                                         // [64] the agent moved in this step's S1 (ego frame still to be updated)
     int* wn;                                             // [32] agents per world of this workgroup
     int* flag;                                           // [4]  0: any world reset this step
     float2* lpv;                                         // [64] LP velocity of each agent (in/out of LP3)
@@ -70,7 +71,7 @@ __host__ __device__ inline int cagym_as(int M, int wpw) { return wpw > 0 ? ((wpw
 
 __host__ __device__ inline size_t cagym_lds2_bytes(int M, int AS = 64) {
     const size_t MP = cagym_mp(M);
-    size_t head = 20 * AS * 8 + AS * 8 + AS * 4 + AS * 4 + AS * 4 + 32 * 4 + 16 + AS * 8 + AS * 4 + AS * 4 + 16;
+    size_t head = 20 * AS * 8 + AS * 8 + AS * 4 + AS * 4 + AS * 4 + AS * 4 + 32 * 4 + 16 + AS * 8 + AS * 4 + AS * 4 + 16;
     // pre-move view: dsq, lines (an ego's row doubles as its linearProgram3 scratch once its group has sorted it),
     // sorted.  post-move view: keys, gap, hit (the OAS rows go straight to HBM).
     size_t pre = AS * MP * 4 + AS * MP * 16 + (size_t)CAGYM_MAXNB * AS * 16;
@@ -90,13 +91,14 @@ __device__ __forceinline__ Lds2 carve_lds2(unsigned char* smem, int M, int AS = 
     W.tcoop = reinterpret_cast<float*>(W.tact + AS);
     W.tst = reinterpret_cast<uint32_t*>(W.tcoop + AS);
     W.tstep = reinterpret_cast<int*>(W.tst + AS);
-    W.wn = W.tstep + AS;
+    W.tmoved = W.tstep + AS;
+    W.wn = W.tmoved + AS;
     W.flag = W.wn + 32;
     W.lpv = reinterpret_cast<float2*>(W.flag + 4);
     W.lpk = reinterpret_cast<int*>(W.lpv + AS);
     W.lpr = reinterpret_cast<float*>(W.lpk + AS);
     W.lpmask = reinterpret_cast<unsigned long long*>(W.lpr + AS);
-    size_t head = 20 * AS * 8 + AS * 8 + AS * 4 + AS * 4 + AS * 4 + 32 * 4 + 16 + AS * 8 + AS * 4 + AS * 4 + 16;
+    size_t head = 20 * AS * 8 + AS * 8 + AS * 4 + AS * 4 + AS * 4 + AS * 4 + 32 * 4 + 16 + AS * 8 + AS * 4 + AS * 4 + 16;
     unsigned char* u = smem + a16(head);
     W.dsq = reinterpret_cast<float*>(u);
     W.lines = reinterpret_cast<float4*>(u + AS * MP * 4);
@@ -363,12 +365,26 @@ __device__ inline void step_core2(const CagymDev& D, const Lds2& W, LaneCtx& C, 
             a0 = (float)d0;
             a1 = (float)d1;
         }
-        take_action(A, a0, a1, D.dt);
-        lds_store_moved(W, A, tid);  // nobody reads the tile here (P1 / LP3 readers are behind their barriers)
+        const bool moved = take_action<false>(A, a0, a1, D.dt);
+        lds_store_moved(W, A, tid);  // nobody reads the tile here (P1 / LP readers are behind their barriers)
+        W.tmoved[tid] = moved ? 1 : 0;
+    } else if (agent_lane) {
+        W.tmoved[tid] = 0;
     }
     __syncthreads();  // post-move tile visible; LP scratch (union, pre-move view) is dead
     STAMP(3);
-    // ---- P2: pair distances, collision tests (env.py:630-655), OAS sort keys ------------------------------
+    // ---- P2: pair distances, collision tests (env.py:630-655), OAS sort keys; the last wave (idle or lightly
+    //      loaded in the unordered-pair loop) runs Dynamics.update_ego_frame of the agents that moved ---------------
+    if (tid >= NT - CAGYM_WAVE) {
+        const int a = tid - (NT - CAGYM_WAVE);
+        if (a < C.wpw * M && W.tmoved[a]) {
+            Agent E;
+            E.px = W.tpx[a]; E.py = W.tpy[a]; E.gx = W.tgx[a]; E.gy = W.tgy[a]; E.h = W.th[a];
+            double prx, pry;
+            update_ego_frame(E, prx, pry);
+            W.tdg[a] = E.dg; W.the[a] = E.he; W.tprx[a] = prx; W.tpry[a] = pry;
+        }
+    }
     if (MT > 0) {
         // one lane per unordered pair: the distance (fp64 sqrt) is shared by both directions
         if (agent_lane) {
