@@ -99,6 +99,16 @@ class BatchedCollisionAvoidanceEnv(object):
                                             self._stream())
         _lib.check(self.L, self.h, rc, "cagym_set_scenarios")
 
+    def sense_occupancy_grid(self, out=None):
+        """'local_grid' observation of every agent (OccupancyGridSensor.sense): uint8 [N, M, 60, 60], 1 = occupied.
+        Parity unpinned (cv2.warpAffine is restated, OpenCV is not installed): see include/cagym.h."""
+        if out is None:
+            out = torch.empty((self.N, self.M, 60, 60), dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = self.L.cagym_occupancy_grid(self.h, out.data_ptr(), self._stream())
+        _lib.check(self.L, self.h, rc, "cagym_occupancy_grid")
+        return out
+
     def generate_scenarios(self, seed, n_agents=None, ego_policy=5, ego_dynamics=0, other_policies=(5, 1), p_b=0.5,
                            other_dynamics=0, side=7.5, min_travel=4.0, min_sep=1.5, radius=0.5, pref_speed=1.0,
                            coop=0.5, max_tries=100000, check=True):

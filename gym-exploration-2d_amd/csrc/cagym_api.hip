@@ -444,6 +444,17 @@ int cagym_laserscan(void* env, float* laserscan, void* stream) {
     return CAGYM_OK;
 }
 
+int cagym_occupancy_grid(void* env, uint8_t* grid, void* stream) {
+    Env* e = reinterpret_cast<Env*>(env);
+    if (!e) return fail(nullptr, CAGYM_E_INVALID, "null env");
+    if (!grid) return fail(e, CAGYM_E_INVALID, "null grid buffer");
+    if (e->cfg.max_obstacles <= 0) return fail(e, CAGYM_E_STATE, "cagym_occupancy_grid needs an env created with max_obstacles > 0");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(k_occupancy_grid, dim3((unsigned)((size_t)e->cfg.n_worlds * e->cfg.max_agents)), dim3(256), 0, st, e->D, grid);
+    HIPCHK(e, hipGetLastError());
+    return CAGYM_OK;
+}
+
 int cagym_get_state(void* env, cagym_state_ptrs* out) {
     Env* e = reinterpret_cast<Env*>(env);
     if (!e || !out) return fail(e, CAGYM_E_INVALID, "null argument");

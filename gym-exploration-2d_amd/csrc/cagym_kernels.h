@@ -463,6 +463,65 @@ __global__ void __launch_bounds__(256) k_laserscan(CagymDev D, float* out) {
     out[gid] = (float)(1 - range / 6);
 }
 
+// OccupancyGridSensor.sense (sensors/OccupancyGridSensor.py:70-98, 131-143; Map.getSubmapByIndices Map.py:81-105):
+// the occupancy raster rotated about the agent's cell by -heading (cv2.getRotationMatrix2D + cv2.warpAffine,
+// bilinear, constant-0 border), 60x60 window around the agent, astype(bool).  One workgroup per agent, 3600 cells.
+// warpAffine restated from OpenCV 4.x imgproc (fixed point: AB_BITS 10, INTER_BITS 5, round_delta 16, cvRound =
+// round half to even); cv2 is absent here, so this sensor is "parity unpinned" (oracle twin: cagym_oracle_grid.c).
+__device__ __forceinline__ int og_src(const uint32_t* map, int x, int y) {  // x = column, y = row; border 0
+    if (x < 0 || y < 0 || x >= CAGYM_MAPD || y >= CAGYM_MAPD) return 0;
+    return map_bit(map, y, x) ? 1 : 0;
+}
+__device__ __forceinline__ int og_submap_start(int c) {
+    long long si = (long long)((double)c - floor(60 / 2.0));  // int(): truncation toward zero
+    if (si < 0) si = 0;
+    if (si + 60 > CAGYM_MAPD - 1) si = CAGYM_MAPD - 1 - 60;
+    return (int)si;
+}
+__global__ void __launch_bounds__(256) k_occupancy_grid(CagymDev D, uint8_t* out) {
+    const size_t a = blockIdx.x;
+    const int world = (int)(a / D.M), slot = (int)(a - (size_t)world * D.M);
+    uint8_t* o = out + a * 3600;
+    const int sidx = (int)(((long long)world + (long long)D.episode[world] * D.N) % D.S);
+    const bool live = slot < D.n_agents[world] && D.map_bits && D.sc_nobst[sidx] > 0;
+    if (!live) {  // inactive slot or empty map: all free
+        for (int q = threadIdx.x; q < 3600; q += blockDim.x) o[q] = 0;
+        return;
+    }
+    const uint32_t* map = D.map_bits + (size_t)sidx * CAGYM_MAPD * CAGYM_MAPW;
+    int gx, gy;
+    world_to_cell(D.px[a], D.py[a], gx, gy);
+    const int sx0 = og_submap_start(gx), sy0 = og_submap_start(gy);
+    double angle = -D.heading[a] * 180 / kPi;
+    angle *= kPi / 180;
+    double beta, alpha;
+    sincos(angle, &beta, &alpha);
+    const double cx = (double)gy, cy = (double)gx;
+    double M0 = alpha, M1 = beta, M2 = (1 - alpha) * cx - beta * cy, M3 = -beta, M4 = alpha, M5 = beta * cx + (1 - alpha) * cy;
+    double Dt = M0 * M4 - M1 * M3;
+    Dt = Dt != 0 ? 1. / Dt : 0;
+    const double A11 = M4 * Dt, A22 = M0 * Dt;
+    M0 = A11; M1 *= -Dt;
+    M3 *= -Dt; M4 = A22;
+    const double b1 = -M0 * M2 - M1 * M5;
+    const double b2 = -M3 * M2 - M4 * M5;
+    M2 = b1; M5 = b2;
+    for (int q = threadIdx.x; q < 3600; q += blockDim.x) {
+        const int r = q / 60, c = q - r * 60;
+        const int y = sx0 + r, x = sy0 + c;
+        const int X0 = __double2int_rn((M1 * y + M2) * 1024) + 16;
+        const int Y0 = __double2int_rn((M4 * y + M5) * 1024) + 16;
+        const int X = (X0 + __double2int_rn(M0 * x * 1024)) >> 5;
+        const int Y = (Y0 + __double2int_rn(M3 * x * 1024)) >> 5;
+        const int sx = X >> 5, sy = Y >> 5, fx = X & 31, fy = Y & 31;
+        int v = og_src(map, sx, sy);
+        if (fx) v |= og_src(map, sx + 1, sy);
+        if (fy) v |= og_src(map, sx, sy + 1);
+        if (fx && fy) v |= og_src(map, sx + 1, sy + 1);
+        o[q] = (uint8_t)v;
+    }
+}
+
 // Map.get_occupancy_grid (Map.py:107-123): one workgroup per scenario, bit-packed output.
 __global__ void __launch_bounds__(256) k_rasterize(const double* obst, const int32_t* nobst, int Kobs, uint32_t* map_bits) {
     const int s = blockIdx.x;

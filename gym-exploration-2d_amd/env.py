@@ -113,7 +113,7 @@ class Config(object):
                 'pos_global_frame': ((2,), (-inf, inf)), 'pref_speed': ((1,), (0, inf)),
                 'num_other_agents': ((1,), (0, inf)), 'other_agent_states': ((10,), (-inf, inf)),
                 'other_agents_states': ((k, 10), (-inf, inf)), 'laserscan': ((cls.LASERSCAN_LENGTH,), (0., 6.)),
-                'use_ppo': ((1,), (0., 1.))}
+                'use_ppo': ((1,), (0., 1.)), 'local_grid': ((60, 60), (0., 1.))}
 
 
 class Box(object):
@@ -288,6 +288,9 @@ class CollisionAvoidanceEnv(object):
         ego = b.obs_ego[0].cpu().numpy().astype(np.float64)
         oas = b.obs_oas[0].cpu().numpy().astype(np.float64)
         laser = b.obs_laser[0].cpu().numpy().astype(np.float64) if b.laserscan else None
+        grid = None
+        if 'local_grid' in Config.STATES_IN_OBS and b.Kobs > 0:  # OccupancyGridSensor (parity unpinned: cv2 restated)
+            grid = b.sense_occupancy_grid()[0].cpu().numpy().astype(bool)
         info = Config.state_info()
         obs = {}
         for i in range(Config.MAX_NUM_AGENTS_IN_ENVIRONMENT):
@@ -320,6 +323,8 @@ class CollisionAvoidanceEnv(object):
                     d[s] = oas[i, 0].copy()
                 elif s == 'laserscan':
                     d[s] = laser[i].copy() if laser is not None else np.zeros(16)
+                elif s == 'local_grid':
+                    d[s] = grid[i].copy() if grid is not None else np.zeros((60, 60), dtype=bool)
                 else:
                     raise KeyError("observation key %r is outside the hot-path scope (SURVEY.md 8(a))" % s)
             obs[i] = d

@@ -201,6 +201,12 @@ int cagym_ig_rollouts(void* env, const double* pose0, const uint64_t* observed0,
                       int max_steps, int xdt, double dt, double fov_rad, double range, uint64_t seed,
                       double* rewards, uint8_t* actions, double* final_pose, uint64_t* observed_out, void* stream);
 
+/* OccupancyGridSensor.sense (sensors/OccupancyGridSensor.py:70-98) for every agent of the current
+ * state: grid DEVICE [N, M, 60, 60] u8 (0 / 1), the 'local_grid' observation: the obstacle raster rotated into the
+ * agent's heading (cv2.warpAffine restated, bilinear, zero border) and cropped around the agent.  Needs
+ * max_obstacles > 0.  PARITY UNPINNED: OpenCV is not available to check the restatement against. */
+int cagym_occupancy_grid(void* env, uint8_t* grid, void* stream);
+
 /* ---- on-device scenario generation ---------------------------------------------------
  * train_agents_random_positions (test_cases.py:1362-1463) for every scenario of the pool, one lane per
  * scenario: per agent draw start x, y and goal x, y ~ U(-side, side) (four draws per attempt, in that order)

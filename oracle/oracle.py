@@ -29,7 +29,7 @@ class Config(C.Structure):
 
 
 def build(force=False):
-    srcs = [os.path.join(HERE, f) for f in ("cagym_oracle.c", "cagym_oracle_ig.c", "cagym_oracle_gen.c", "cagym_oracle.h", "Makefile")]
+    srcs = [os.path.join(HERE, f) for f in ("cagym_oracle.c", "cagym_oracle_ig.c", "cagym_oracle_gen.c", "cagym_oracle_grid.c", "cagym_oracle.h", "Makefile")]
     if force or not os.path.exists(LIB) or any(os.path.getmtime(s) > os.path.getmtime(LIB) for s in srcs):
         subprocess.check_call(["make", "-s", "-C", HERE, "libcagym_oracle.so"])
     return LIB
@@ -70,6 +70,7 @@ def lib():
         L.cao_ig_rollout.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
                                                         C.c_double, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p,
                                                         C.c_void_p, C.c_void_p]
+        L.cao_occupancy_grid.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_void_p]
         L.cao_generate_scenarios.restype = C.c_int
         L.cao_generate_scenarios.argtypes = [C.c_uint64] + [C.c_int] * 10 + [C.c_double] * 7 + [C.c_void_p] * 5
         _lib = L
@@ -248,3 +249,12 @@ def generate_scenarios(S, M, seed, **kw):
                                       P["min_travel"], P["min_sep"], P["radius"], P["pref_speed"], P["coop"], _p(a6),
                                       _p(pol), _p(dyn), _p(na), _p(cp))
     return a6, pol, dyn, na, cp, nf
+
+
+def occupancy_grid(static_map, px, py, heading):
+    """OccupancyGridSensor.sense (sensors/OccupancyGridSensor.py:70-98) for one agent: static_map [300,300] bool
+    (rasterize()), returns the [60,60] bool local grid.  PARITY UNPINNED (cv2 absent): see cagym_oracle_grid.c."""
+    m = np.ascontiguousarray(np.asarray(static_map) != 0, dtype=np.uint8)
+    out = np.zeros((60, 60), dtype=np.uint8)
+    lib().cao_occupancy_grid(_p(m), float(px), float(py), float(heading), _p(out))
+    return out.astype(bool)

@@ -24,6 +24,8 @@ for _ in range(150):
     env.step()
 env.ga3c_states()
 orc.generate_scenarios(60, 10, seed=3, n_min=2, n_max=10)
+for pose in ((0.0, 0.0, 0.3), (14.9, -14.9, 2.0), (40.0, 7.0, -1.0)):
+    orc.occupancy_grid(orc.rasterize([(2, 2, 10, 10), (-10, 2, -2, 10)]), *pose)
 z = np.load(os.path.join(%(root)r, "tests", "golden", "ig_primitives.npz"))
 edf, d2 = orc.edt(orc.rasterize(z["rects__obstacles"]))
 for p in z["rects__vis_poses"][:10]:
