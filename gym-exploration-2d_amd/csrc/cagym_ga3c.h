@@ -2,7 +2,7 @@
 // input normalisation -> LSTM(64) over the observed agents -> concat host state -> FC 68->256 -> FC 256->256 ->
 // FC 256->256 (all ReLU) -> logits 256->11 -> argmax -> action table (network.py:8-17) -> (pref_speed*a0, a1)).
 //
-// One workgroup (256 lanes) evaluates AG = 32 agents.  Lane n owns output neuron n of every layer for all 32
+// One workgroup (256 lanes) evaluates AG = 32 agents; three workgroups share a CU (49 KB of LDS each).  Lane n owns output neuron n of every layer for all 32
 // agents (32 fp32 accumulators in registers); the layer input is kept in LDS as [k][agent] so one
 // ds_read_b128 feeds four FMAs, and weight row k (256 floats, [in][out] as TensorFlow stores them) is one
 // coalesced, L2-resident load per k.  fp32 like the reference's TF graph; the 683 KB of weights are shared
@@ -54,32 +54,31 @@ __global__ void __launch_bounds__(256) k_ga3c_forward(const float* __restrict__ 
                                                       const int32_t* __restrict__ agent_idx, int B,
                                                       const double* __restrict__ pref, float* ext_actions,
                                                       int32_t* action_index, float* probs) {
+    // LDS: 49 KB per workgroup => three workgroups (12 waves) per CU.  The activations are updated IN PLACE (every
+    // lane finishes reading the layer input before any lane writes its output row: one extra barrier per layer), the
+    // other-agent features are re-read from the state rows each LSTM step, and the FC-1 input [host(4), h(64)] is
+    // rows 3..70 of the LSTM input tile.
     __shared__ __attribute__((aligned(16))) float u[(7 + GA_H) * GA_AG];  // LSTM input [k][g]: 7 features + h
     __shared__ __attribute__((aligned(16))) float cst[GA_H * GA_AG];       // cell state [unit][g]
-    __shared__ __attribute__((aligned(16))) float seq[10 * 7 * GA_AG];     // normalised other-agent features [t][f][g]
-    __shared__ __attribute__((aligned(16))) float za[GA_W * GA_AG];        // layer outputs [n][g]
-    __shared__ __attribute__((aligned(16))) float zb[GA_W * GA_AG];
+    __shared__ __attribute__((aligned(16))) float za[GA_W * GA_AG];        // gates / layer activations [n][g]
     __shared__ float hostv[4 * GA_AG];                                     // normalised host state [f][g]
     __shared__ int nseq[GA_AG];
+    __shared__ int rowof[GA_AG];
     __shared__ float logit[GA_AG * 12];
     const int n = threadIdx.x, tile = blockIdx.x * GA_AG;
-    // ---- load + normalise (network.py:125-148): x_hat = (x - avg) / std ---------------------------------
-    for (int e = n; e < GA_AG * 75; e += 256) {
-        const int g = e / 75, f = e - g * 75;
+    // ---- load + normalise the host part (network.py:125-148): x_hat = (x - avg) / std -----------------------
+    for (int e = n; e < GA_AG * 5; e += 256) {
+        const int g = e / 5, f = e - g * 5;
         const int a = tile + g < B ? agent_idx[tile + g] : -1;
         const float x = a >= 0 ? state[(size_t)a * 76 + 1 + f] : 0.f;
         if (f == 0) {
             int ns = (int)x;
             nseq[g] = a >= 0 ? (ns < 0 ? 0 : (ns > 10 ? 10 : ns)) : 0;
-        } else if (f < 5) {
+            rowof[g] = a;
+        } else {
             const float avg = f == 3 ? 1.0f : (f == 4 ? 0.5f : 0.0f);
             const float sd = f == 1 ? 5.0f : (f == 2 ? 3.14f : 1.0f);
             hostv[(f - 1) * GA_AG + g] = (x - avg) / sd;
-        } else {
-            const int t = (f - 5) / 7, c = (f - 5) - t * 7;
-            const float avg = c == 4 ? 0.5f : (c == 6 ? 1.0f : 0.0f);
-            const float sd = (c == 0 || c == 1 || c == 5) ? 5.0f : 1.0f;
-            seq[(t * 7 + c) * GA_AG + g] = (x - avg) / sd;
         }
     }
     for (int e = n; e < GA_H * GA_AG; e += 256) {
@@ -91,7 +90,14 @@ __global__ void __launch_bounds__(256) k_ga3c_forward(const float* __restrict__ 
     for (int g = 0; g < GA_AG; g++) tmax = nseq[g] > tmax ? nseq[g] : tmax;
     // ---- LSTM (network.py:83-90) -----------------------------------------------------------------------
     for (int t = 0; t < tmax; t++) {
-        for (int e = n; e < 7 * GA_AG; e += 256) u[e] = seq[t * 7 * GA_AG + e];
+        if (n < 7 * GA_AG) {  // other-agent features of step t, normalised: u[c][g]
+            const int c = n / GA_AG, g = n - c * GA_AG;
+            const int a = rowof[g];
+            const float x = a >= 0 ? state[(size_t)a * 76 + 6 + t * 7 + c] : 0.f;
+            const float avg = c == 4 ? 0.5f : (c == 6 ? 1.0f : 0.0f);
+            const float sd = (c == 0 || c == 1 || c == 5) ? 5.0f : 1.0f;
+            u[n] = (x - avg) / sd;
+        }
         __syncthreads();
         float acc[GA_AG];
         const float b = Wb[GA_OFF_BL + n];
@@ -113,47 +119,36 @@ __global__ void __launch_bounds__(256) k_ga3c_forward(const float* __restrict__ 
         }
         __syncthreads();
     }
-    // ---- layer1: concat[host(4), h(64)] -> 256, ReLU (network.py:92-93) ------------------------------------
-    for (int e = n; e < 4 * GA_AG; e += 256) zb[e] = hostv[e];
-    for (int e = n; e < GA_H * GA_AG; e += 256) zb[4 * GA_AG + e] = u[7 * GA_AG + e];
+    // ---- layer1: concat[host(4), h(64)] -> 256, ReLU (network.py:92-93): input = rows 3..70 of u -----------
+    for (int e = n; e < 4 * GA_AG; e += 256) u[3 * GA_AG + e] = hostv[e];
     __syncthreads();
     {
         float acc[GA_AG];
         const float b = Wb[GA_OFF_B1 + n];
 #pragma unroll
         for (int g = 0; g < GA_AG; g++) acc[g] = b;
-        ga_dense(zb, Wb + GA_OFF_W1, 4 + GA_H, n, acc);
+        ga_dense(u + 3 * GA_AG, Wb + GA_OFF_W1, 4 + GA_H, n, acc);
         float4* zo = reinterpret_cast<float4*>(za + n * GA_AG);
 #pragma unroll
         for (int q = 0; q < GA_AG / 4; q++)
             zo[q] = make_float4(fmaxf(acc[4 * q], 0.f), fmaxf(acc[4 * q + 1], 0.f), fmaxf(acc[4 * q + 2], 0.f), fmaxf(acc[4 * q + 3], 0.f));
     }
     __syncthreads();
-    // ---- layer2, fullyconnected1 (network.py:95, 47) ---------------------------------------------------------
-    {
+    // ---- layer2, fullyconnected1 (network.py:95, 47), in place ------------------------------------------------
+#pragma unroll 1
+    for (int layer = 0; layer < 2; layer++) {
         float acc[GA_AG];
-        const float b = Wb[GA_OFF_B2 + n];
+        const float b = Wb[(layer == 0 ? GA_OFF_B2 : GA_OFF_B3) + n];
 #pragma unroll
         for (int g = 0; g < GA_AG; g++) acc[g] = b;
-        ga_dense(za, Wb + GA_OFF_W2, GA_W, n, acc);
-        float4* zo = reinterpret_cast<float4*>(zb + n * GA_AG);
-#pragma unroll
-        for (int q = 0; q < GA_AG / 4; q++)
-            zo[q] = make_float4(fmaxf(acc[4 * q], 0.f), fmaxf(acc[4 * q + 1], 0.f), fmaxf(acc[4 * q + 2], 0.f), fmaxf(acc[4 * q + 3], 0.f));
-    }
-    __syncthreads();
-    {
-        float acc[GA_AG];
-        const float b = Wb[GA_OFF_B3 + n];
-#pragma unroll
-        for (int g = 0; g < GA_AG; g++) acc[g] = b;
-        ga_dense(zb, Wb + GA_OFF_W3, GA_W, n, acc);
+        ga_dense(za, Wb + (layer == 0 ? GA_OFF_W2 : GA_OFF_W3), GA_W, n, acc);
+        __syncthreads();  // every lane has read the whole input before any output row replaces it
         float4* zo = reinterpret_cast<float4*>(za + n * GA_AG);
 #pragma unroll
         for (int q = 0; q < GA_AG / 4; q++)
             zo[q] = make_float4(fmaxf(acc[4 * q], 0.f), fmaxf(acc[4 * q + 1], 0.f), fmaxf(acc[4 * q + 2], 0.f), fmaxf(acc[4 * q + 3], 0.f));
+        __syncthreads();
     }
-    __syncthreads();
     // ---- logits_p 256 -> 11 (network.py:50) -------------------------------------------------------------------
     for (int e = n; e < GA_AG * 11; e += 256) {
         const int g = e / 11, o = e - g * 11;
