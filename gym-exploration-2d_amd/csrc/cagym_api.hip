@@ -498,9 +498,14 @@ int cagym_ga3c_forward(void* env, const float* weights, const float* state, cons
     if (!e) return fail(nullptr, CAGYM_E_INVALID, "null env");
     if (!weights || !state || !agent_idx || B < 0) return fail(e, CAGYM_E_INVALID, "bad arguments");
     if (B == 0) return CAGYM_OK;
-    hipLaunchKernelGGL(k_ga3c_forward, dim3((unsigned)((B + GA_AG - 1) / GA_AG)), dim3(256), 0,
-                       reinterpret_cast<hipStream_t>(stream), weights, state, agent_idx, B, e->D.pref, ext_actions,
-                       action_index, probs);
+    // 32 agents per workgroup reuse every weight 32 times; small batches take 16 so that each CU still gets >= 2 workgroups
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (B <= 16 * 1024)
+        hipLaunchKernelGGL(k_ga3c_forward<16>, dim3((unsigned)((B + 15) / 16)), dim3(256), 0, st, weights, state, agent_idx, B,
+                           e->D.pref, ext_actions, action_index, probs);
+    else
+        hipLaunchKernelGGL(k_ga3c_forward<32>, dim3((unsigned)((B + 31) / 32)), dim3(256), 0, st, weights, state, agent_idx, B,
+                           e->D.pref, ext_actions, action_index, probs);
     HIPCHK(e, hipGetLastError());
     return CAGYM_OK;
 }

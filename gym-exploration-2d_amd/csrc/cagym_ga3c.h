@@ -2,7 +2,8 @@
 // input normalisation -> LSTM(64) over the observed agents -> concat host state -> FC 68->256 -> FC 256->256 ->
 // FC 256->256 (all ReLU) -> logits 256->11 -> argmax -> action table (network.py:8-17) -> (pref_speed*a0, a1)).
 //
-// One workgroup (256 lanes) evaluates AG = 32 agents; three workgroups share a CU (49 KB of LDS each).  Lane n owns output neuron n of every layer for all 32
+// One workgroup (256 lanes) evaluates AG = 32 agents (16 for small batches, so that every CU gets work); three
+// workgroups share a CU (49 KB of LDS each at AG = 32).  Lane n owns output neuron n of every layer for all 32
 // agents (32 fp32 accumulators in registers); the layer input is kept in LDS as [k][agent] so one
 // ds_read_b128 feeds four FMAs, and weight row k (256 floats, [in][out] as TensorFlow stores them) is one
 // coalesced, L2-resident load per k.  fp32 like the reference's TF graph; the 683 KB of weights are shared
@@ -13,7 +14,6 @@
 #pragma once
 #include "cagym_device.h"
 
-#define GA_AG 32
 #define GA_H 64
 #define GA_W 256
 // packed weight blob offsets (floats)
@@ -30,6 +30,7 @@
 #define GA_NWEIGHTS (GA_OFF_BP + 11)
 
 // acc[g] += in[k][g] * w for the 32 agents of the tile; `in` is LDS [K][32]
+template <int GA_AG>
 __device__ __forceinline__ void ga_dense(const float* __restrict__ in, const float* __restrict__ Wt, int K, int n,
                                          float (&acc)[GA_AG]) {
     for (int k = 0; k < K; k++) {
@@ -50,6 +51,7 @@ __device__ __forceinline__ float ga_sigmoid(float x) { return 1.0f / (1.0f + exp
 
 // state: [*, 76] rows (cagym_ga3c_state); agent_idx[B]: rows to evaluate (flat world*M + slot).
 // ext_actions [N*M, 2] receives (pref_speed * a0, a1) for those agents; action_index / probs optional.
+template <int GA_AG>
 __global__ void __launch_bounds__(256) k_ga3c_forward(const float* __restrict__ Wb, const float* __restrict__ state,
                                                       const int32_t* __restrict__ agent_idx, int B,
                                                       const double* __restrict__ pref, float* ext_actions,
@@ -90,7 +92,7 @@ __global__ void __launch_bounds__(256) k_ga3c_forward(const float* __restrict__ 
     for (int g = 0; g < GA_AG; g++) tmax = nseq[g] > tmax ? nseq[g] : tmax;
     // ---- LSTM (network.py:83-90) -----------------------------------------------------------------------
     for (int t = 0; t < tmax; t++) {
-        if (n < 7 * GA_AG) {  // other-agent features of step t, normalised: u[c][g]
+        if (n < 7 * GA_AG) {  // other-agent features of step t, normalised: u[c][g] (7 * AG <= 256 lanes)
             const int c = n / GA_AG, g = n - c * GA_AG;
             const int a = rowof[g];
             const float x = a >= 0 ? state[(size_t)a * 76 + 6 + t * 7 + c] : 0.f;
@@ -103,7 +105,7 @@ __global__ void __launch_bounds__(256) k_ga3c_forward(const float* __restrict__ 
         const float b = Wb[GA_OFF_BL + n];
 #pragma unroll
         for (int g = 0; g < GA_AG; g++) acc[g] = b;
-        ga_dense(u, Wb + GA_OFF_WL, 7 + GA_H, n, acc);
+        ga_dense<GA_AG>(u, Wb + GA_OFF_WL, 7 + GA_H, n, acc);
         float4* zo = reinterpret_cast<float4*>(za + n * GA_AG);
 #pragma unroll
         for (int q = 0; q < GA_AG / 4; q++) zo[q] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
@@ -127,7 +129,7 @@ __global__ void __launch_bounds__(256) k_ga3c_forward(const float* __restrict__ 
         const float b = Wb[GA_OFF_B1 + n];
 #pragma unroll
         for (int g = 0; g < GA_AG; g++) acc[g] = b;
-        ga_dense(u + 3 * GA_AG, Wb + GA_OFF_W1, 4 + GA_H, n, acc);
+        ga_dense<GA_AG>(u + 3 * GA_AG, Wb + GA_OFF_W1, 4 + GA_H, n, acc);
         float4* zo = reinterpret_cast<float4*>(za + n * GA_AG);
 #pragma unroll
         for (int q = 0; q < GA_AG / 4; q++)
@@ -141,7 +143,7 @@ __global__ void __launch_bounds__(256) k_ga3c_forward(const float* __restrict__ 
         const float b = Wb[(layer == 0 ? GA_OFF_B2 : GA_OFF_B3) + n];
 #pragma unroll
         for (int g = 0; g < GA_AG; g++) acc[g] = b;
-        ga_dense(za, Wb + (layer == 0 ? GA_OFF_W2 : GA_OFF_W3), GA_W, n, acc);
+        ga_dense<GA_AG>(za, Wb + (layer == 0 ? GA_OFF_W2 : GA_OFF_W3), GA_W, n, acc);
         __syncthreads();  // every lane has read the whole input before any output row replaces it
         float4* zo = reinterpret_cast<float4*>(za + n * GA_AG);
 #pragma unroll
