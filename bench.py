@@ -172,6 +172,18 @@ def main():
         traffic = None
         if (N, M, args.policy, args.per_step_launch) == (4096, 10, "rvo", False) and steps_per_launch == 64:
             traffic = 423.9 * N * M * steps_per_launch / (launch_ms * 1e-3) / 1e9  # GB/s, comparable to `achieved`
+        # measured device-to-device copy ceiling next to the vendor HBM figure: read + write of 1 GiB
+        src = torch.empty(1 << 30, dtype=torch.uint8, device=device)
+        dst = torch.empty_like(src)
+        dst.copy_(src)
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record()
+        for _ in range(5):
+            dst.copy_(src)
+        c1.record()
+        torch.cuda.synchronize(device)
+        copy_gbs = 5 * 2 * (1 << 30) / (c0.elapsed_time(c1) * 1e-3) / 1e9
+        del src, dst
         line = {
             "metric": "env-steps/sec (whole node), 4096 worlds x 10 agents",
             "value": value, "unit": "env-steps/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
@@ -188,6 +200,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": kernel_name,
                          "launch_ms": launch_ms, "alg_bytes_per_agent_step": balg,
+                         "measured_d2d_copy_GBs": copy_gbs,
                          "alg_bytes_per_launch": balg * N * M * steps_per_launch,
                          "traffic_bytes_per_launch": None if traffic is None else 423.9 * N * M * steps_per_launch},
             "episodes": st,
