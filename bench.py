@@ -127,6 +127,7 @@ def main():
                 # episode-stats all-gather on a side stream, overlapping the next launch
                 local = stats_mod.pack_episode_stats(env.episode_stats())
                 side.wait_stream(torch.cuda.current_stream(device))
+                local.record_stream(side)  # allocated on the main stream, read by the collective on the side stream
                 with torch.cuda.stream(side):
                     gathered = stats_mod.all_gather_episode_stats(local)
         if side is not None:
