@@ -50,7 +50,9 @@ struct Lds2 {
     float2* lpv;                                         // [64] LP velocity of each agent (in/out of LP3)
     int* lpk;                                            // [64] line where linearProgram2 failed (or nn)
     float* lpr;                                          // [64] maxSpeed of the ego (LP radius)
-    unsigned long long* lpmask;                          // [1]  agents that need linearProgram3
+    unsigned long long* lpmask;                          // [1]  (unused)
+    float2* lpc;                                         // [64] pref velocity clipped to maxSpeed = LP start; LP result afterwards
+    int* busy;                                           // [64] some half-plane of the ego is violated by its LP start
     // union, pre-move view.  Rows are padded to MP = roundup(M, 4) entries and unused entries hold
     // sentinels, so the rank loops are branch-free 16-byte LDS reads.
     float* dsq;      // [64*MP]   squared centre distance ego->neighbour (+inf = not a neighbour)
@@ -71,7 +73,7 @@ __host__ __device__ inline int cagym_as(int M, int wpw) { return wpw > 0 ? ((wpw
 
 __host__ __device__ inline size_t cagym_lds2_bytes(int M, int AS = 64) {
     const size_t MP = cagym_mp(M);
-    size_t head = 20 * AS * 8 + AS * 8 + AS * 4 + AS * 4 + AS * 4 + AS * 4 + 32 * 4 + 16 + AS * 8 + AS * 4 + AS * 4 + 16;
+    size_t head = 20 * AS * 8 + AS * 8 + AS * 4 + AS * 4 + AS * 4 + AS * 4 + 32 * 4 + 16 + AS * 8 + AS * 4 + AS * 4 + 16 + AS * 8 + AS * 4;
     // pre-move view: dsq, lines (an ego's row doubles as its linearProgram3 scratch once its group has sorted it),
     // sorted.  post-move view: keys, gap, hit (the OAS rows go straight to HBM).
     size_t pre = AS * MP * 4 + AS * MP * 16 + (size_t)CAGYM_MAXNB * AS * 16;
@@ -98,7 +100,9 @@ __device__ __forceinline__ Lds2 carve_lds2(unsigned char* smem, int M, int AS = 
     W.lpk = reinterpret_cast<int*>(W.lpv + AS);
     W.lpr = reinterpret_cast<float*>(W.lpk + AS);
     W.lpmask = reinterpret_cast<unsigned long long*>(W.lpr + AS);
-    size_t head = 20 * AS * 8 + AS * 8 + AS * 4 + AS * 4 + AS * 4 + AS * 4 + 32 * 4 + 16 + AS * 8 + AS * 4 + AS * 4 + 16;
+    W.lpc = reinterpret_cast<float2*>(W.lpmask + 2);
+    W.busy = reinterpret_cast<int*>(W.lpc + AS);
+    size_t head = 20 * AS * 8 + AS * 8 + AS * 4 + AS * 4 + AS * 4 + AS * 4 + 32 * 4 + 16 + AS * 8 + AS * 4 + AS * 4 + 16 + AS * 8 + AS * 4;
     unsigned char* u = smem + a16(head);
     W.dsq = reinterpret_cast<float*>(u);
     W.lines = reinterpret_cast<float4*>(u + AS * MP * 4);
@@ -196,21 +200,25 @@ struct UnorderedPairs {
     }
 };
 
-// Compact list of the agent lanes that solve an ORCA LP in the next step (wave 0, inside `if (agent_lane)`).
-__device__ __forceinline__ void publish_rvo_list(const Lds2& W, int tid, bool is_rvo) {
-    const unsigned long long m = __ballot(is_rvo);
-    if (is_rvo) W.lpk[__popcll(m & ((1ull << tid) - 1ull))] = tid;
-    if (tid == 0) W.lpmask[0] = (unsigned long long)__popcll(m);
-}
-
 // prefVelocity = pref_speed (goal - pos) / |goal - pos| and maxSpeed of agent a (RVOPolicy.py:65-85, as orca_ego),
 // from the agent record in LDS into the slots the next LP phase reads (lpv doubles as the LP result afterwards).
 __device__ __forceinline__ void publish_pref_velocity(const Lds2& W, int a) {
     const double gx = W.tgx[a] - W.tpx[a], gy = W.tgy[a] - W.tpy[a];
     const double pref = W.tpref[a];
     const double sc = pref / norm2(gx, gy);
-    W.lpv[a] = make_float2((float)(sc * gx), (float)(sc * gy));
-    W.lpr[a] = (float)pref;
+    const float ox = (float)(sc * gx), oy = (float)(sc * gy), radius = (float)pref;
+    W.lpv[a] = make_float2(ox, oy);
+    W.lpr[a] = radius;
+    // linearProgram2's starting point: the optimisation velocity clipped to maxSpeed.  An ego none of whose half-planes
+    // is violated there keeps it as its new velocity (the LP never moves it), so only the others ("busy") get an LP group.
+    float cx = ox, cy = oy;
+    if (ox * ox + oy * oy > radius * radius) {
+        const float inv = 1.0f / sqrtf(ox * ox + oy * oy);
+        cx = ox * inv * radius;
+        cy = oy * inv * radius;
+    }
+    W.lpc[a] = make_float2(cx, cy);
+    W.busy[a] = 0;
 }
 
 // One env.step() of the workgroup's worlds.  Agent registers A live on wave 0 (tid < 64) only; the pair
@@ -259,11 +267,17 @@ __device__ inline void step_core2(const CagymDev& D, const Lds2& W, LaneCtx& C, 
                     dq = g.d2;
                     if (on_a) {
                         const float c = W.tcoop[a];
-                        W.lines[a * MP + q.j] = make_float4(vax + c * g.ux, vay + c * g.uy, g.zx, g.zy);
+                        const float4 ln = make_float4(vax + c * g.ux, vay + c * g.uy, g.zx, g.zy);
+                        W.lines[a * MP + q.j] = ln;
+                        const float2 s0 = W.lpc[a];
+                        if (detf(ln.z, ln.w, ln.x - s0.x, ln.y - s0.y) > 0.0f) W.busy[a] = 1;
                     }
                     if (on_b) {
                         const float c = W.tcoop[b];
-                        W.lines[b * MP + q.i] = make_float4((float)W.tvx[b] - c * g.ux, (float)W.tvy[b] - c * g.uy, -g.zx, -g.zy);
+                        const float4 ln = make_float4((float)W.tvx[b] - c * g.ux, (float)W.tvy[b] - c * g.uy, -g.zx, -g.zy);
+                        W.lines[b * MP + q.i] = ln;
+                        const float2 s0 = W.lpc[b];
+                        if (detf(ln.z, ln.w, ln.x - s0.x, ln.y - s0.y) > 0.0f) W.busy[b] = 1;
                     }
                 }
                 W.dsq[a * MP + q.j] = on_a ? dq : INFINITY;
@@ -281,9 +295,12 @@ __device__ inline void step_core2(const CagymDev& D, const Lds2& W, LaneCtx& C, 
                 const float pex = (float)W.tpx[q.a], pey = (float)W.tpy[q.a];
                 const float dx = pex - (float)W.tpx[b], dy = pey - (float)W.tpy[b];
                 dq = dx * dx + dy * dy;
-                W.lines[q.a * MP + q.j] = orca_line(pex, pey, (float)W.tvx[q.a], (float)W.tvy[q.a],
-                                                    (float)((1 + 15e-2) * W.tr[q.a]), W.tcoop[q.a], (float)D.dt,
-                                                    W.tpx[b], W.tpy[b], W.tvx[b], W.tvy[b], W.tr[b]);
+                const float4 ln = orca_line(pex, pey, (float)W.tvx[q.a], (float)W.tvy[q.a],
+                                            (float)((1 + 15e-2) * W.tr[q.a]), W.tcoop[q.a], (float)D.dt,
+                                            W.tpx[b], W.tpy[b], W.tvx[b], W.tvy[b], W.tr[b]);
+                W.lines[q.a * MP + q.j] = ln;
+                const float2 s0 = W.lpc[q.a];
+                if (detf(ln.z, ln.w, ln.x - s0.x, ln.y - s0.y) > 0.0f) W.busy[q.a] = 1;
             }
             W.dsq[q.a * MP + q.j] = dq;
             if (q.j == M - 1)
@@ -297,8 +314,18 @@ __device__ inline void step_core2(const CagymDev& D, const Lds2& W, LaneCtx& C, 
     //      previous S2 (or the kernel prologue) published ----------------------------------------------------
     if (any_rvo) {
         constexpr int GW = MT > 0 && MT <= 5 ? 4 : (MT > 0 && MT <= 10 ? CAGYM_GW10 : 16), NG = NT / GW;
-        const int cnt = (int)W.lpmask[0];
+        // every wave builds the same compact list of busy egos (identical values to identical LDS slots)
+        int cnt;
+        {
+            const int lane = tid & (CAGYM_WAVE - 1);
+            const bool fl = lane < C.wpw * M && W.busy[lane] != 0;
+            const unsigned long long bm = __ballot(fl);
+            cnt = __popcll(bm);
+            if (fl) W.lpk[__popcll(bm & ((1ull << lane) - 1ull))] = lane;
+        }
         const int g = tid / GW, j = tid & (GW - 1);
+        // busy egos are packed into as few waves as possible (dealing them round-robin over the waves was slower at
+        // every launch size: 301 vs 312 M env-steps/s at 4096 worlds, 507 vs 521 M at 65536)
         for (int base = 0; base < cnt; base += NG) {
             const int idx = base + g;
             if (idx < cnt) {
@@ -333,7 +360,7 @@ __device__ inline void step_core2(const CagymDev& D, const Lds2& W, LaneCtx& C, 
                 STAMP(10);  // list read + ranking
                 // linearProgram3 scratch: the ego's own (now dead) row of unsorted half-planes, MP >= nn entries
                 orca_lp_group<GW>(W.sorted, W.lines + a * MP, a, j, nn, rad, pv.x, pv.y, vx, vy, AS);
-                if (j == 0) W.lpv[a] = make_float2(vx, vy);
+                if (j == 0) W.lpc[a] = make_float2(vx, vy);
                 STAMP(11);  // LP of group 0's agent
             }
         }
@@ -357,7 +384,7 @@ __device__ inline void step_core2(const CagymDev& D, const Lds2& W, LaneCtx& C, 
                     break;
                 case CAGYM_POL_CARRL: d0 = 1.0; d1 = carrl_heading(ext ? (int)ext[2 * aidx] : 0); break;
                 case CAGYM_POL_RVO: {
-                    const float2 v = W.lpv[tid];
+                    const float2 v = W.lpc[tid];  // LP result, or the clipped preferred velocity of an ego that needed none
                     orca_post(A, v.x, v.y, D.dt, d0, d1);
                     break;
                 }
@@ -536,8 +563,6 @@ __device__ inline void step_core2(const CagymDev& D, const Lds2& W, LaneCtx& C, 
         }
         W.tst[tid] = A.st;
         if (tid == 0) W.flag[0] = any_reset ? 1 : 0;
-        if (any_rvo)
-            publish_rvo_list(W, tid, C.valid && C.active && !(A.st & CAGYM_FLAG_DONE) && ST_POLICY(A.st) == CAGYM_POL_RVO);
     }
     __syncthreads();
     STAMP(5);
@@ -640,7 +665,6 @@ __global__ void __launch_bounds__(NT, (NT <= 256 ? 3 : 2)) k_rollout2(CagymDev D
         }
         lds_store_agent(W, A, threadIdx.x);
         if (C.wl < C.wpw && C.slot == 0) W.wn[C.wl] = C.valid ? C.n : 0;
-        publish_rvo_list(W, threadIdx.x, C.valid && C.active && !(A.st & CAGYM_FLAG_DONE) && ST_POLICY(A.st) == CAGYM_POL_RVO);
         publish_pref_velocity(W, threadIdx.x);
     }
     const size_t NM = (size_t)D.N * M;
@@ -686,7 +710,6 @@ __global__ void __launch_bounds__(NT) k_step2(CagymDev D, const float* ext, Cagy
         }
         lds_store_agent(W, A, threadIdx.x);
         if (C.wl < C.wpw && C.slot == 0) W.wn[C.wl] = C.valid ? C.n : 0;
-        publish_rvo_list(W, threadIdx.x, C.valid && C.active && !(A.st & CAGYM_FLAG_DONE) && ST_POLICY(A.st) == CAGYM_POL_RVO);
         publish_pref_velocity(W, threadIdx.x);
     }
     step_core2<NT, MT, WPWT, AUTO_RESET>(D, W, C, ext, out, ep_ret, ep_len, any_rvo != 0);
