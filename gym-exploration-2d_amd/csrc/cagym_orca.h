@@ -262,172 +262,11 @@ __device__ inline void orca_action(const NbrTile& T, float4* L, float4* P, int l
     orca_solve(L, P, lane, nn, E, A, dt, out_speed, out_dh);
 }
 
-// linearProgram2 (directionOpt = false) with the half-planes in registers and both loops fully unrolled.
-// linearProgram1's clipping is written without early exits: tLeft only grows and tRight only shrinks, so
-// "tLeft > tRight at some point" == "tLeft > tRight at the end", and the "parallel and outside" test is an OR;
-// the i independent (den, num, t) triples of line i then overlap instead of forming a chain of dependent LDS
-// reads and divisions.  Results are identical to orca_lp2/orca_lp1 (checked bitwise against generation 1).
-__device__ inline int orca_lp2_unrolled(const float4* L, int lane, int n, float radius, float ox, float oy, float& rx,
-                                        float& ry, int stride = CAGYM_WAVE) {
-    float4 ln[CAGYM_MAXNB];
-#pragma unroll
-    for (int i = 0; i < CAGYM_MAXNB; i++) ln[i] = L[i * stride + lane];  // slots >= n: stale but in bounds, unused
-    if (ox * ox + oy * oy > radius * radius) {
-        float inv = 1.0f / sqrtf(ox * ox + oy * oy);
-        rx = ox * inv * radius;
-        ry = oy * inv * radius;
-    } else {
-        rx = ox;
-        ry = oy;
-    }
-    int fail = n;
-    bool done = false;
-#pragma unroll
-    for (int i = 0; i < CAGYM_MAXNB; i++) {
-        if (done || i >= n) continue;
-        if (!(detf(ln[i].z, ln[i].w, ln[i].x - rx, ln[i].y - ry) > 0.0f)) continue;
-        // linearProgram1(i)
-        const float dot = ln[i].x * ln[i].z + ln[i].y * ln[i].w;
-        const float disc = dot * dot + radius * radius - (ln[i].x * ln[i].x + ln[i].y * ln[i].y);
-        bool ok = !(disc < 0.0f);
-        float tl = 0.f, tr = 0.f;
-        if (ok) {
-            const float sq = sqrtf(disc);
-            tl = -dot - sq;
-            tr = -dot + sq;
-            bool bad = false;
-#pragma unroll
-            for (int j = 0; j < i; j++) {
-                const float den = detf(ln[i].z, ln[i].w, ln[j].z, ln[j].w);
-                const float num = detf(ln[j].z, ln[j].w, ln[i].x - ln[j].x, ln[i].y - ln[j].y);
-                const bool par = fabsf(den) <= RVO_EPS;
-                const float t = num / den;
-                bad |= par && (num < 0.0f);
-                if (!par) {
-                    if (den >= 0.0f) tr = tr < t ? tr : t;
-                    else tl = tl > t ? tl : t;
-                }
-            }
-            ok = !bad && !(tl > tr);
-        }
-        if (ok) {
-            float t = ln[i].z * (ox - ln[i].x) + ln[i].w * (oy - ln[i].y);
-            if (t < tl) t = tl;
-            else if (t > tr) t = tr;
-            rx = ln[i].x + t * ln[i].z;
-            ry = ln[i].y + t * ln[i].w;
-        } else {
-            fail = i;  // result keeps the value it had before this line (tempResult)
-            done = true;
-        }
-    }
-    return fail;
-}
-
-// ---- cooperative linearProgram3 --------------------------------------------------------------------
-// One ego per 16-lane group, lane j <-> half-plane j.  Same arithmetic as orca_lp3/orca_lp2/orca_lp1 above:
-// the interval clipping of linearProgram1 (tLeft = max, tRight = min, "parallel and outside" / tLeft > tRight
-// failures) does not depend on the order in which the earlier lines are visited, so it is a 16-lane
-// min/max/any reduction; the outer loops over i (violated line) and k (projected line) stay sequential.
-// All 16 lanes of a group run the same control flow; groups of one wave may diverge from each other.
-__device__ __forceinline__ float grp16_max(float v) {
-    v = fmaxf(v, __shfl_xor(v, 8, 16));
-    v = fmaxf(v, __shfl_xor(v, 4, 16));
-    v = fmaxf(v, __shfl_xor(v, 2, 16));
-    return fmaxf(v, __shfl_xor(v, 1, 16));
-}
-__device__ __forceinline__ float grp16_min(float v) {
-    v = fminf(v, __shfl_xor(v, 8, 16));
-    v = fminf(v, __shfl_xor(v, 4, 16));
-    v = fminf(v, __shfl_xor(v, 2, 16));
-    return fminf(v, __shfl_xor(v, 1, 16));
-}
-
-__device__ inline void orca_lp3_group(const float4* L, float4* P, int a, int j, int nn, int begin, float radius,
-                                      float& rx, float& ry, int stride = CAGYM_WAVE) {
-    const int gbase = (threadIdx.x & 63) & ~15;
-    float distance = 0.0f;
-    for (int i = begin; i < nn; i++) {
-        const float4 li = L[i * stride + a];
-        if (!(detf(li.z, li.w, li.x - rx, li.y - ry) > distance)) continue;
-        // projected line of lane j (j < i); `have` = it exists (not "parallel, same direction")
-        bool have = false;
-        float4 pj = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (j < i) {
-            const float4 lj = L[j * stride + a];
-            const float d = detf(li.z, li.w, lj.z, lj.w);
-            have = true;
-            if (fabsf(d) <= RVO_EPS) {
-                if (li.z * lj.z + li.w * lj.w > 0.0f) have = false;
-                pj.x = 0.5f * (li.x + lj.x);
-                pj.y = 0.5f * (li.y + lj.y);
-            } else {
-                const float s = detf(lj.z, lj.w, li.x - lj.x, li.y - lj.y) / d;
-                pj.x = li.x + s * li.z;
-                pj.y = li.y + s * li.w;
-            }
-            const float ddx = lj.z - li.z, ddy = lj.w - li.w;
-            const float inv = 1.0f / sqrtf(ddx * ddx + ddy * ddy);
-            pj.z = ddx * inv;
-            pj.w = ddy * inv;
-            if (have) P[j * stride + a] = pj;
-        }
-        const uint32_t hmask = (uint32_t)((__ballot(have) >> gbase) & 0xffffull);
-        const float ox = -li.w, oy = li.z;
-        const float tx = rx, ty = ry;
-        float qx = ox * radius, qy = oy * radius;  // linearProgram2, directionOpt
-        bool failed = false;
-        for (int k = 0; k < i && !failed; k++) {
-            if (!((hmask >> k) & 1u)) continue;
-            const float4 pk = P[k * stride + a];
-            if (!(detf(pk.z, pk.w, pk.x - qx, pk.y - qy) > 0.0f)) continue;
-            // linearProgram1(k), directionOpt
-            const float dot = pk.x * pk.z + pk.y * pk.w;
-            const float disc = dot * dot + radius * radius - (pk.x * pk.x + pk.y * pk.y);
-            if (disc < 0.0f) { failed = true; break; }
-            const float sq = sqrtf(disc);
-            float tl = -dot - sq, tr = -dot + sq;
-            float ltl = -INFINITY, ltr = INFINITY;
-            bool lfail = false;
-            if (j < k && have) {
-                const float den = detf(pk.z, pk.w, pj.z, pj.w);
-                const float num = detf(pj.z, pj.w, pk.x - pj.x, pk.y - pj.y);
-                if (fabsf(den) <= RVO_EPS) {
-                    if (num < 0.0f) lfail = true;
-                } else {
-                    const float t = num / den;
-                    if (den >= 0.0f) ltr = t;
-                    else ltl = t;
-                }
-            }
-            tl = fmaxf(tl, grp16_max(ltl));
-            tr = fminf(tr, grp16_min(ltr));
-            const bool anyfail = ((__ballot(lfail) >> gbase) & 0xffffull) != 0ull;
-            if (anyfail || tl > tr) { failed = true; break; }
-            const float t = (ox * pk.z + oy * pk.w > 0.0f) ? tr : tl;
-            qx = pk.x + t * pk.z;
-            qy = pk.y + t * pk.w;
-        }
-        if (failed) { rx = tx; ry = ty; }
-        else { rx = qx; ry = qy; }
-        distance = detf(li.z, li.w, li.x - rx, li.y - ry);
-    }
-}
-
 // ---- linearProgram2 + linearProgram3 of one ego on a GW-lane group (GW = 4, 8 or 16) ---------------------------
 // Lane j of the group holds half-plane j.  Line i only ever meets lines j < i, so GW lanes serve nn <= GW + 1
 // half-planes.  linearProgram1's interval clipping is a min/max/any reduction over the lanes j < i (same
-// argument as orca_lp3_group above); the reductions are DPP row operations (no LDS round trip).  All lanes of
+// argument as for linearProgram3 below); the reductions are DPP row operations (no LDS round trip).  All lanes of
 // a group run the same control flow; the groups of one wave may diverge from each other.
-template <int CTRL>
-__device__ __forceinline__ float dpp_f32(float v) {
-    const int x = __builtin_bit_cast(int, v);
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(x, x, CTRL, 0xf, 0xf, false));
-}
-#define CAGYM_DPP_QUAD_XOR1 0xB1   // quad_perm [1,0,3,2]
-#define CAGYM_DPP_QUAD_XOR2 0x4E   // quad_perm [2,3,0,1]
-#define CAGYM_DPP_ROW_MIRROR 0x140
-#define CAGYM_DPP_ROW_HALF_MIRROR 0x141
 // One reduction level = ONE instruction: v_max/min_f32 with a DPP source operand (the builtin route costs a DPP
 // move plus canonicalising maxes per level).  s_nop 1 covers the VALU-write -> DPP-read hazard, which the
 // compiler's hazard recogniser does not see inside inline assembly.  Operands are never NaN here.
