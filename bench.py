@@ -4,8 +4,9 @@
 Workload (N=1): BASELINE.json configs[2] -- 4096 worlds x 10 agents, every agent RVO/ORCA (ego LP on
 device) + OtherAgentsStates sensor, synthetic random-goal episodes (SURVEY.md 8(d) rule), auto-reset
 from a pool of 8x4096 scenarios.  One "step" = one env.step() of all worlds of a rank.  Steps are
-issued through cagym_rollout (ROLL env steps per launch, agent state in registers, every step writes
-its full observation / reward / flag tensors to HBM slice t of a trajectory buffer).
+issued through cagym_rollout (ROLL env steps per launch, agent records on chip, every step writes
+its full observation / reward / flag tensors to HBM slice t of a trajectory buffer).  ROLL defaults to 512: a launch
+ends with its slowest workgroup, and longer roll-outs average the per-step variation of the LP work out.
 
 Multi-GPU (--gpus N under torch.distributed.run): worlds are independent, each rank owns its own 4096
 worlds (weak scaling); the only collective is the RCCL all-gather of per-world episode statistics,
@@ -63,7 +64,8 @@ def main():
     ap.add_argument("--worlds", type=int, default=4096, help="worlds per GPU")
     ap.add_argument("--agents", type=int, default=10)
     ap.add_argument("--policy", default="rvo", choices=["rvo", "noncoop"])
-    ap.add_argument("--roll", type=int, default=64, help="env steps per launch")
+    ap.add_argument("--roll", type=int, default=512, help="env steps per launch (64: 313, 128: 334, 256: 345, 512: 360 M env-steps/s: "
+                    "a launch ends with its slowest workgroup, longer roll-outs average the per-step variation out)")
     ap.add_argument("--per-step-launch", action="store_true", help="one cagym_step launch per env step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pool-factor", type=int, default=8, help="scenario pool size = factor x worlds")
@@ -168,11 +170,13 @@ def main():
                                         spec.get(M, "256, 0, 0" if M <= 12 else "512, 0, 0"))
         achieved = balg * N * M * steps_per_launch / (launch_ms * 1e-3) / 1e9
         # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate
-        # rocprofv3 --pmc passes; profiles/r1/bench_4096x10_rvo_pmc_hbm.txt): 423.9 B per agent-step, measured on
-        # this workload at 64 steps per launch; not re-measured live, so null for any other shape.
+        # rocprofv3 --pmc passes; profiles/r1/bench_4096x10_rvo_pmc_hbm.txt): 418.5 B per agent-step at 512 steps per
+        # launch, 423.9 B at 64 (per-step outputs 417.7 B + 395 B of state in/out per agent and launch); measured on this
+        # workload only and not re-measured live, so null for any other shape.
         traffic = None
-        if (N, M, args.policy, args.per_step_launch) == (4096, 10, "rvo", False) and steps_per_launch == 64:
-            traffic = 423.9 * N * M * steps_per_launch / (launch_ms * 1e-3) / 1e9  # GB/s, comparable to `achieved`
+        traffic_per_agent_step = 417.7 + 395.0 / steps_per_launch
+        if (N, M, args.policy, args.per_step_launch) == (4096, 10, "rvo", False):
+            traffic = traffic_per_agent_step * N * M * steps_per_launch / (launch_ms * 1e-3) / 1e9  # GB/s, comparable to `achieved`
         # measured device-to-device copy ceiling next to the vendor HBM figure: read + write of 1 GiB
         src = torch.empty(1 << 30, dtype=torch.uint8, device=device)
         dst = torch.empty_like(src)
@@ -203,7 +207,7 @@ def main():
                          "launch_ms": launch_ms, "alg_bytes_per_agent_step": balg,
                          "measured_d2d_copy_GBs": copy_gbs,
                          "alg_bytes_per_launch": balg * N * M * steps_per_launch,
-                         "traffic_bytes_per_launch": None if traffic is None else 423.9 * N * M * steps_per_launch},
+                         "traffic_bytes_per_launch": None if traffic is None else traffic_per_agent_step * N * M * steps_per_launch},
             "episodes": st,
         }
         if not args.no_cpu_baseline:

@@ -6,12 +6,12 @@ mkdir -p $O
 export TMPDIR=/tmp
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 echo bench done
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o run -- python3 bench.py --steps 1280 --warmup 256 --no-cpu-baseline > $O/bench_under_rocprof.json 2>/dev/null
-rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $O/pmc_fetch -o run -- python3 bench.py --steps 256 --warmup 64 --no-cpu-baseline > /dev/null 2>&1
-rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $O/pmc_write -o run -- python3 bench.py --steps 256 --warmup 64 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o run -- python3 bench.py --steps 2048 --warmup 512 --no-cpu-baseline > $O/bench_under_rocprof.json 2>/dev/null
+rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $O/pmc_fetch -o run -- python3 bench.py --steps 1024 --warmup 512 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $O/pmc_write -o run -- python3 bench.py --steps 1024 --warmup 512 --no-cpu-baseline > /dev/null 2>&1
 PMC="SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_LDS"
-rocprofv3 --kernel-trace --output-format csv --pmc $PMC -d $O/pmc_sq_4096 -o run -- python3 bench.py --steps 128 --warmup 64 --no-cpu-baseline > /dev/null 2>&1
-rocprofv3 --kernel-trace --output-format csv --pmc $PMC -d $O/pmc_sq_65536 -o run -- python3 bench.py --steps 128 --warmup 64 --no-cpu-baseline --worlds 65536 --pool-factor 2 > /dev/null 2>&1
+rocprofv3 --kernel-trace --output-format csv --pmc $PMC -d $O/pmc_sq_4096 -o run -- python3 bench.py --steps 1024 --warmup 512 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --output-format csv --pmc $PMC -d $O/pmc_sq_65536 -o run -- python3 bench.py --steps 128 --warmup 64 --roll 64 --no-cpu-baseline --worlds 65536 --pool-factor 2 > /dev/null 2>&1
 rocprofv3 --kernel-trace --output-format csv --pmc TCC_HIT_sum TCC_MISS_sum -d $O/pmc_ig_l2 -o run -- python3 tools/ig_queries.py > /dev/null 2>&1
 echo pmc done
 for d in pmc_fetch pmc_write pmc_sq_4096 pmc_sq_65536; do python tools/pmc_summary.py $O/$d k_rollout2 > $O/$d.txt; done
@@ -24,16 +24,20 @@ for N in 16384 65536 262144; do
 done
 echo "N=1048576 roll=4" >> $O/sweep.txt
 python bench.py --no-cpu-baseline --worlds 1048576 --roll 4 --steps 32 --warmup 8 --pool-factor 1 --scenarios device >> $O/sweep.txt
+for R in 64 128 256; do
+  echo "N=4096 roll=$R (steps per launch)" >> $O/sweep.txt
+  python bench.py --no-cpu-baseline --roll $R >> $O/sweep.txt
+done
 echo "per-step launches (cagym_step_autoreset)" >> $O/sweep.txt
 python bench.py --no-cpu-baseline --per-step-launch --steps 1024 --warmup 128 >> $O/sweep.txt
 echo "cfg2 4096x4 NonCooperative" >> $O/sweep.txt
 python bench.py --no-cpu-baseline --agents 4 --policy noncoop >> $O/sweep.txt
 echo "2048x20 RVO" >> $O/sweep.txt
-python bench.py --no-cpu-baseline --worlds 2048 --agents 20 >> $O/sweep.txt
+python bench.py --no-cpu-baseline --worlds 2048 --agents 20 --roll 256 >> $O/sweep.txt
 echo sweep done
 python tools/bench_rows.py > $O/bench_rows.json 2> $O/bench_rows.err
 echo rows done
-CAGYM_BENCH_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 512 --warmup 64 --no-cpu-baseline > $O/rehearsal_2ranks_gloo.json 2> $O/rehearsal_2ranks_gloo.err
+CAGYM_BENCH_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 512 --warmup 64 --roll 64 --no-cpu-baseline > $O/rehearsal_2ranks_gloo.json 2> $O/rehearsal_2ranks_gloo.err
 echo rehearsal done
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1
 echo smoke done

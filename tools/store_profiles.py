@@ -35,27 +35,28 @@ def dur(path):
             return float(l.split("avg_ns=")[1])
 
 
+d0 = json.load(open(O + "bench_default.json"))
 f, w = avg(O + "pmc_fetch.txt", "FETCH_SIZE"), avg(O + "pmc_write.txt", "WRITE_SIZE")
-units = 64 * 4096 * 10
+units = int(d0["config"]["steps_per_launch"]) * 4096 * 10
 tot = (2 * f + w) * 1024
 import csv
 ks = list(csv.reader(open(O + "stats/run_kernel_stats.csv")))[1]
 open(P + "bench_4096x10_rvo_pmc_hbm.txt", "w").write(
-    "kernel k_rollout2<256, 10, 4, true> (round-1 final), 64 env steps x 4096 worlds x 10 agents per dispatch (2 621 440 agent-steps)\n"
-    "rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -- python3 bench.py --steps 256 --warmup 64 --no-cpu-baseline   (own pass)\n"
-    "rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -- python3 bench.py --steps 256 --warmup 64 --no-cpu-baseline   (own pass)\n"
+    "kernel k_rollout2<256, 10, 4, true> (round-1 final), %d env steps x 4096 worlds x 10 agents per dispatch (%d agent-steps)\n"
+    "rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -- python3 bench.py --steps 1024 --warmup 512 --no-cpu-baseline   (own pass)\n"
+    "rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -- python3 bench.py --steps 1024 --warmup 512 --no-cpu-baseline   (own pass)\n"
     "(tools/final_profile.sh; per-dispatch averages by tools/pmc_summary.py)\n"
     "FETCH_SIZE avg/dispatch = %.0f KB -> x2 (gfx950 counts 64 B per 128-B request) = %.2f MB\n"
     "WRITE_SIZE avg/dispatch = %.4g KB = %.1f MB\n"
-    "traffic = %.1f MB/dispatch = %.1f B per agent-step; algorithmic bytes (517 B/agent-step) = 1355.28 MB/dispatch\n"
+    "traffic = %.1f MB/dispatch = %.1f B per agent-step; algorithmic bytes (517 B/agent-step) = %.2f MB/dispatch\n"
     "(the OAS rows are stored straight from the pair lanes as 8-B pieces: write traffic is unchanged vs LDS-staged 16-B stores, L2 merges them)\n"
     "kernel duration in the two passes: %.3f / %.3f ms; --kernel-trace --stats run: %.4f ms average over %s launches\n"
     "(bench_4096x10_rvo_kernel_stats.csv); bench.py's own HIP-event figure in the same session: %.3f ms per launch (bench_default.json)\n" % (
-        f, 2 * f * 1024 / 1e6, w, w * 1024 / 1e6, tot / 1e6, tot / units, dur(O + "pmc_fetch.txt") / 1e6, dur(O + "pmc_write.txt") / 1e6,
+        units // 40960, units, f, 2 * f * 1024 / 1e6, w, w * 1024 / 1e6, tot / 1e6, tot / units, 517.0 * units / 1e6, dur(O + "pmc_fetch.txt") / 1e6, dur(O + "pmc_write.txt") / 1e6,
         float(ks[3]) / 1e6, ks[1], d["roofline"]["launch_ms"]))
 print("traffic B/agent-step %.1f" % (tot / units))
-txt = ["rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_LDS -- python3 bench.py --steps 128 --warmup 64 --no-cpu-baseline [--worlds 65536 --pool-factor 2]",
-       "per-dispatch averages (64 env steps per dispatch); SQ_ACTIVE_INST_VALU in quad-cycles summed over SIMDs; GRBM_GUI_ACTIVE summed over the 8 XCDs"]
+txt = ["rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_LDS -- python3 bench.py --steps 1024 --warmup 512 --no-cpu-baseline | ... --steps 128 --warmup 64 --roll 64 --worlds 65536 --pool-factor 2",
+       "per-dispatch averages (512 env steps per dispatch at 4096 worlds, 64 at 65536); SQ_ACTIVE_INST_VALU in quad-cycles summed over SIMDs; GRBM_GUI_ACTIVE summed over the 8 XCDs"]
 for tag in ("4096", "65536"):
     p = O + "pmc_sq_%s.txt" % tag
     txt.append("--- %s worlds" % tag)
