@@ -306,6 +306,9 @@ static void sense_world(cao_env* e, int w) {
 }
 
 void cao_reset(cao_env* e, const uint8_t* world_mask) {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
     for (int w = 0; w < e->N; w++) {
         if (world_mask && !world_mask[w]) continue;
         e->nagents[w] = e->sc_nagents[w];
@@ -686,8 +689,13 @@ static void done_world(cao_env* e, int w) {
 }
 
 void cao_step(cao_env* e, const double* ext_actions) {
-    float act[64][2];
+    /* worlds are independent (no cross-world term in env.py): with -fopenmp the loop is shared between threads, used
+     * only by bench.py's cpu_baseline (OMP_NUM_THREADS); results do not depend on the thread count */
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
     for (int w = 0; w < e->N; w++) {
+        float act[64][2];
         int n = e->nagents[w];
         size_t base = (size_t)w * e->M;
         for (int i = 0; i < n; i++) select_action(e, w, i, ext_actions, act[i]); /* all select first ... */
@@ -699,6 +707,17 @@ void cao_step(cao_env* e, const double* ext_actions) {
         rewards_world(e, w);
         sense_world(e, w);
         done_world(e, w);
+    }
+}
+
+/* bench.py's cpu_baseline loop in one call: n_steps x { step every world; restart the worlds whose game is over on the
+ * same scenario }, i.e. what the DummyVecEnv loop of experiments/src/env_utils.py:29-62 does per env. */
+void cao_run(cao_env* e, int n_steps) {
+    for (int t = 0; t < n_steps; t++) {
+        cao_step(e, NULL);
+        int any = 0;
+        for (int w = 0; w < e->N; w++) any |= e->u[CAO_U_GAME_OVER][w];
+        if (any) cao_reset(e, e->u[CAO_U_GAME_OVER]);
     }
 }
 

@@ -56,6 +56,7 @@ void cao_set_scenario(cao_env* e, const double* agents6, const double* heading0,
 void cao_reset(cao_env* e, const uint8_t* world_mask);
 /* ext_actions[N,M,2] doubles (may be NULL when no agent needs one). */
 void cao_step(cao_env* e, const double* ext_actions);
+void cao_run(cao_env* e, int n_steps); /* n_steps x (step all worlds, restart finished ones) */
 
 /* zero-copy views for the tests; field ids below */
 enum { CAO_F_POS = 0, CAO_F_VEL, CAO_F_HEADING, CAO_F_SPEED, CAO_F_DELTA_HEADING, CAO_F_DIST_TO_GOAL,

@@ -50,6 +50,7 @@ def lib():
         L.cao_set_scenario.argtypes = [C.c_void_p] + [C.c_void_p] * 8
         L.cao_reset.argtypes = [C.c_void_p, C.c_void_p]
         L.cao_step.argtypes = [C.c_void_p, C.c_void_p]
+        L.cao_run.argtypes = [C.c_void_p, C.c_int]
         for n, t in (("cao_f64", C.c_double), ("cao_u8", C.c_uint8), ("cao_i32", C.c_int32)):
             getattr(L, n).restype = C.POINTER(t)
             getattr(L, n).argtypes = [C.c_void_p, C.c_int]
@@ -121,6 +122,10 @@ class OracleEnv(object):
         a = None if ext_actions is None else np.ascontiguousarray(
             np.asarray(ext_actions, dtype=np.float64).reshape(self.N, self.M, 2))
         self.L.cao_step(self.h, _p(a))
+
+    def run(self, n_steps):
+        """n_steps x (step every world, restart the finished ones on the same scenario) without leaving C."""
+        self.L.cao_run(self.h, int(n_steps))
 
     def f(self, name):
         w = self.K * 10 if name == "oas" else F_WIDTH[name]

@@ -23,6 +23,7 @@ env.reset()
 for _ in range(150):
     env.step()
 env.ga3c_states()
+env.run(40)
 orc.generate_scenarios(60, 10, seed=3, n_min=2, n_max=10)
 for pose in ((0.0, 0.0, 0.3), (14.9, -14.9, 2.0), (40.0, 7.0, -1.0)):
     orc.occupancy_grid(orc.rasterize([(2, 2, 10, 10), (-10, 2, -2, 10)]), *pose)
