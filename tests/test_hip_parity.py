@@ -84,7 +84,7 @@ def test_hip_matches_oracle_batch(M, policy):
 
 
 def test_mixed_policies_dynamics_and_ragged_worlds():
-    """Ragged n_agents (including 1-agent and empty-slot worlds), every policy/dynamics id, external actions."""
+    """Ragged n_agents (including 1-agent, EMPTY and full worlds), every policy/dynamics id, external actions."""
     N, M, T = 64, 10, 40
     rng = np.random.default_rng(3)
     a6 = scen.random_worlds_fast(N, M, seed=11)
@@ -93,6 +93,7 @@ def test_mixed_policies_dynamics_and_ragged_worlds():
     n_agents = rng.integers(1, M + 1, N).astype(np.int32)
     n_agents[0] = 1
     n_agents[1] = M
+    n_agents[2] = 0
     hip = _hip(N=N, M=M, game_over_mode=2)
     cpu = orc.OracleEnv(N=N, M=M, game_over_mode=2)
     for e in (hip, cpu):
