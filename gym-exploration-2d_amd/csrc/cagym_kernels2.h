@@ -2,14 +2,17 @@
 //
 // Why: with one lane per agent a 4096 x 10 batch is 683 lone waves on 1024 SIMDs; SQ counters showed
 // ~11.5 k instructions per wave-step, ~85 % of them the O(M^2) neighbour loops, 47 % of cycles in waits
-// (profiles/r1/*pmc_sq.txt).  Here a workgroup of NT threads owns the same wpw = 64/M worlds, and a step
-// alternates between
-//   S phases: lane-dense PER-AGENT work on wave 0 (policy/LP solve, dynamics, reward, done, reset), and
-//   P phases: lane-dense PER-PAIR work on all NT lanes (ORCA half-planes + neighbour ranks, pair
-//             distances / collision tests, OAS sort ranks and rows),
-// separated by workgroup barriers, so the serial chain per step is ~10x shorter and several waves per
-// SIMD overlap each other's latency.  Arithmetic is shared with generation 1 (cagym_device.h,
-// cagym_orca.h): both generations produce bit-identical results (tests/test_hip_parity.py).
+// (profiles/r1/history/*pmc_sq.txt).  Here a workgroup of NT threads owns a few whole worlds, the agent records
+// live in LDS, and a step alternates between
+//   S phases: per-AGENT work on wave 0 (action maps + dynamics; reward / done / reset),
+//   P phases: per-PAIR work on all NT lanes (ORCA half-planes per unordered pair; pair distances and collision
+//             tests per unordered pair; OAS ranks and rows per directed pair, stored straight to HBM), and
+//   the LP phase: linearProgram2/3 of every ego with a violated half-plane on an 8-lane group (lane j <-> line j,
+//             DPP reductions),
+// separated by workgroup barriers; idle lanes of the pair phases run the ego-frame update and prepare the next
+// step's LP inputs.  DESIGN.md section 4 has the full list and the measurements behind each choice.  Arithmetic is
+// shared with generation 1 (cagym_device.h, cagym_orca.h): both generations produce bit-identical results
+// (tests/test_hip_parity.py).
 #pragma once
 #include "cagym_kernels.h"
 
@@ -47,10 +50,10 @@ struct Lds2 {
     int* tmoved;                                         // [64] the agent moved in this step's S1 (ego frame still to be updated)
     int* wn;                                             // [32] agents per world of this workgroup
     int* flag;                                           // [4]  0: any world reset this step
-    float2* lpv;                                         // [64] LP velocity of each agent (in/out of LP3)
-    int* lpk;                                            // [64] line where linearProgram2 failed (or nn)
+    float2* lpv;                                         // [64] preferred (optimisation) velocity of each ego
+    int* lpk;                                            // [64] compact list of the busy egos (LP phase)
     float* lpr;                                          // [64] maxSpeed of the ego (LP radius)
-    unsigned long long* lpmask;                          // [1]  (unused)
+    unsigned long long* lpmask;                          // [2]  padding (keeps the 8-byte alignment of what follows)
     float2* lpc;                                         // [64] pref velocity clipped to maxSpeed = LP start; LP result afterwards
     int* busy;                                           // [64] some half-plane of the ego is violated by its LP start
     // union, pre-move view.  Rows are padded to MP = roundup(M, 4) entries and unused entries hold

@@ -31,10 +31,10 @@ for _ in range(R):
     env.rollout(T, out=traj)
 torch.cuda.synchronize()
 env.L.cagym_debug_stamps(out, 0)
-names = ["S0 publish+bar", "P1a lines+bar", "P1b rank+bar", "S1c post+dynamics+bar", "P2 pairs+bar", "S2 reward/done+bar",
-         "P3 OAS rows+bar", "store", "LP: wait for the other groups + barrier", "-", "LP: list + ego set-up (group 0)",
-         "LP: LP2/LP3 of group 0's agent"]
+names = ["S0 barrier", "P1 half-planes per unordered pair+bar", "(unused)", "S1 action maps + dynamics+bar", "P2 pair distances+bar",
+         "S2 reward/done/reset+bar", "P3 OAS rows", "ego observation store", "LP: wait for the other groups + barrier", "(unused)",
+         "LP: list + ranking (group 0)", "LP: linearProgram2/3 of group 0's ego"]
 tot = sum(out[:12])
-print("s_memtime ticks (100 MHz constant clock?) per step, workgroup 0; total %.1f per step" % (tot / (R * T)))
+print("s_memtime ticks per step, workgroup 0 (about 1.5 shader cycles per tick under this load); total %.1f per step" % (tot / (R * T)))
 for i, n in enumerate(names[:12]):
     print("  %-22s %10.1f  %5.1f %%" % (n, out[i] / (R * T), 100.0 * out[i] / tot))
