@@ -1,16 +1,23 @@
 #!/usr/bin/env python3
 """bench.py -- env-steps/sec of the batched CollisionAvoidanceEnv on N MI355X (BASELINE.json metric).
 
-Workload (N=1): BASELINE.json configs[2] -- 4096 worlds x 10 agents, every agent RVO/ORCA (ego LP on
-device) + OtherAgentsStates sensor, synthetic random-goal episodes (SURVEY.md 8(d) rule), auto-reset
-from a pool of 8x4096 scenarios.  One "step" = one env.step() of all worlds of a rank.  Steps are
-issued through cagym_rollout (ROLL env steps per launch, agent records on chip, every step writes
-its full observation / reward / flag tensors to HBM slice t of a trajectory buffer).  ROLL defaults to 512: a launch
-ends with its slowest workgroup, and longer roll-outs average the per-step variation of the LP work out.
+Workload (N=1, --config cfg3, the default): BASELINE.json configs[2] -- 4096 worlds x 10 agents, every agent RVO/ORCA
+(ego LP on device) + OtherAgentsStates sensor, synthetic random-goal episodes (SURVEY.md 8(d) rule), auto-reset from a
+pool of 8x4096 scenarios.  One "step" = one env.step() of all worlds of a rank.  Steps are issued through cagym_rollout
+(up to --roll env steps per launch, agent records on chip, every step writes its full observation / reward / flag
+tensors to HBM slice t of a trajectory buffer).
 
-Multi-GPU (--gpus N under torch.distributed.run): worlds are independent, each rank owns its own 4096
-worlds (weak scaling); the only collective is the RCCL all-gather of per-world episode statistics,
-issued once per rollout launch on a side stream.
+Timing (repeats, median): after --warmup untimed steps the block of EXACTLY --steps steps is timed
+`repeats` times, each time bracketed by barrier + torch.cuda.synchronize() on both sides and max-reduced over ranks;
+`ms_per_step` / `value` are the MEDIAN block (min / max beside it).
+
+Multi-GPU: `python bench.py --gpus N` with no RANK in the environment starts N one-GPU ranks itself
+(torch.distributed.run, before anything touches the GPU in this process); under a launcher (RANK set) it is one rank.
+Worlds are independent, each rank owns its own 4096 worlds (weak scaling); the only collective is the RCCL all-gather
+of per-world episode statistics, issued once per rollout launch on a side stream.
+
+Other rows of SURVEY 8(d): --config cfg2 (4096 x 4 NonCooperative), cfg4 (8192 x 10: GA3C-CADRL agent 0 + 9 RVO among
+rectangles, LaserScan), cfg5 (2048 x 20 information-gain env part + planner primitives).
 
 Prints ONE JSON line on rank 0.
 """
@@ -18,27 +25,63 @@ import argparse
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-B_ALG = {"noncoop": 133.0 + 384.0, "rvo": 517.0}  # algorithmic bytes / agent-step
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
+# algorithmic bytes per agent-step: 68 B state in + 60 B out + 5 B reward/flags = 133, OAS + ego 384 (K = 9)
+B_STATE, B_OAS9, B_OAS19, B_LASER = 133.0, 384.0, 784.0, 64.0
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2048)
+    ap.add_argument("--warmup", type=int, default=256)
+    ap.add_argument("--config", default="cfg3", choices=["cfg2", "cfg3", "cfg4", "cfg5"])
+    ap.add_argument("--worlds", type=int, default=None, help="worlds per GPU (default: the config's)")
+    ap.add_argument("--agents", type=int, default=None)
+    ap.add_argument("--policy", default=None, choices=["rvo", "noncoop"])
+    ap.add_argument("--roll", type=int, default=512, help="max env steps per launch")
+    ap.add_argument("--repeats", type=int, default=0, help="timed blocks (0 = at least 5, more while the blocks are short)")
+    ap.add_argument("--per-step-launch", action="store_true", help="one cagym_step_autoreset launch per env step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pool-factor", type=int, default=8, help="scenario pool size = factor x worlds")
+    ap.add_argument("--scenarios", default="host", choices=["host", "device"],
+                    help="host: numpy rejection sampler + upload; device: cagym_generate_scenarios (same rule)")
+    return ap.parse_args(argv)
+
+
+def self_launch(args):
+    """--gpus N without a launcher: start N ranks (one per GPU) as children of this process, which has not touched
+    the GPU (no torch import yet), and pass their output and exit code through."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def cpu_baseline(M, policy_id, seconds=12.0, worlds=2048, threads=None):
     """The CPU restatement (oracle, "port") timed on this host's cores: the world loop of cao_step is shared between
     OpenMP threads (worlds are independent), bounded sample."""
-    threads = threads or min(os.cpu_count() or 1, 16)
-    os.environ["OMP_NUM_THREADS"] = str(threads)  # read by libgomp when the oracle library starts its first team
+    import numpy as np
     from oracle import oracle as orc
     scen = importlib.import_module("gym-exploration-2d_amd.scenarios")
     orc.build()
+    want = threads or min(os.cpu_count() or 1, 16)
+    threads = int(orc.lib().cao_set_threads(int(want)))  # the team size actually in force (omp_get_max_threads)
     a6 = scen.random_worlds_fast(worlds, M, seed=99)
     env = orc.OracleEnv(N=worlds, M=M, game_over_mode=1)
     env.set_scenario(a6, policy_id, scen.DYN_UNICYCLE, coop=np.full((worlds, M), 0.5))
@@ -54,32 +97,29 @@ def cpu_baseline(M, policy_id, seconds=12.0, worlds=2048, threads=None):
             break
     return {"value": worlds * steps / el, "unit": "env-steps/s", "cores": threads, "kind": "port",
             "sample": "%d worlds x %d agents, %d steps, %.1f s, C oracle (oracle/cagym_oracle.c) with its world loop on "
-                      "%d OpenMP threads, finished worlds restart inside the C loop, same policy/scenario rule"
+                      "%d OpenMP threads (omp_get_max_threads), finished worlds restart inside the C loop, same policy/scenario rule"
                       % (worlds, M, steps, el, threads)}
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2048)
-    ap.add_argument("--warmup", type=int, default=256)
-    ap.add_argument("--worlds", type=int, default=4096, help="worlds per GPU")
-    ap.add_argument("--agents", type=int, default=10)
-    ap.add_argument("--policy", default="rvo", choices=["rvo", "noncoop"])
-    ap.add_argument("--roll", type=int, default=512, help="env steps per launch (64: 313, 128: 334, 256: 345, 512: 360 M env-steps/s: "
-                    "a launch ends with its slowest workgroup, longer roll-outs average the per-step variation out)")
-    ap.add_argument("--per-step-launch", action="store_true", help="one cagym_step launch per env step")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--pool-factor", type=int, default=8, help="scenario pool size = factor x worlds")
-    ap.add_argument("--scenarios", default="host", choices=["host", "device"],
-                    help="host: numpy rejection sampler + upload; device: cagym_generate_scenarios (same rule)")
-    args = ap.parse_args()
+    args = parse_args()
+    if args.gpus < 1:
+        sys.exit("--gpus must be >= 1")
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(self_launch(args))
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world_size:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node %d, or without a launcher)"
+                 % (args.gpus, world_size, args.gpus))
+    if args.config in ("cfg4", "cfg5"):
+        rows = importlib.import_module("tools.bench_rows")
+        return rows.main_from_bench(args)
 
+    import numpy as np
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world_size = int(os.environ.get("WORLD_SIZE", "1"))
     # one process per GPU; CAGYM_BENCH_BACKEND=gloo + several ranks on one card is the 1-GPU rehearsal of the N>1 path
     backend = os.environ.get("CAGYM_BENCH_BACKEND", "nccl")
     dev_index = local_rank if backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
@@ -97,8 +137,11 @@ def main():
     scen = importlib.import_module("gym-exploration-2d_amd.scenarios")
     stats_mod = importlib.import_module("gym-exploration-2d_amd.stats")
     BEnv = importlib.import_module("gym-exploration-2d_amd.batched_env").BatchedCollisionAvoidanceEnv
-    N, M = args.worlds, args.agents
-    pol = scen.POLICY_RVO if args.policy == "rvo" else scen.POLICY_NONCOOP
+    defaults = {"cfg2": (4096, 4, "noncoop"), "cfg3": (4096, 10, "rvo")}[args.config]
+    N = args.worlds or defaults[0]
+    M = args.agents or defaults[1]
+    policy = args.policy or defaults[2]
+    pol = scen.POLICY_RVO if policy == "rvo" else scen.POLICY_NONCOOP
     S = args.pool_factor * N
     env = BEnv(N, M, n_scenarios=S, game_over_mode="all", device=device)
     if args.scenarios == "device":
@@ -143,20 +186,40 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
+    def timed_block():
+        """EXACTLY --steps steps between two barrier + synchronize brackets; returns (wall s maxed over ranks, device ms, launches)."""
+        barrier()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()
+        launches = run(args.steps)
+        ev1.record()
+        barrier()
+        el = time.perf_counter() - t0
+        if world_size > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, ev0.elapsed_time(ev1), launches
+
     run(args.warmup)
     barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    launches = run(args.steps)
-    ev1.record()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world_size > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    dev_ms = ev0.elapsed_time(ev1)
+    blocks = [timed_block()]
+    if args.repeats > 0:
+        repeats = args.repeats
+    else:  # at least 5 blocks; short blocks are repeated until about 2 s are on the clock (same count on every rank)
+        repeats = int(min(400, max(5, 2.0 / max(blocks[0][0], 1e-6))))
+        if world_size > 1:
+            r = torch.tensor([repeats], dtype=torch.int64, device=device)
+            dist.broadcast(r, 0)
+            repeats = int(r.item())
+    while len(blocks) < repeats:
+        blocks.append(timed_block())
+    walls = sorted(b[0] for b in blocks)
+    elapsed = walls[len(walls) // 2]  # median block
+    dev_sorted = sorted(b[1] for b in blocks)
+    dev_ms = dev_sorted[len(dev_sorted) // 2]
+    launches = blocks[0][2]
 
     st = stats_mod.summarize(gathered if gathered is not None else stats_mod.pack_episode_stats(env.episode_stats()))
     if rank == 0:
@@ -164,20 +227,15 @@ def main():
         value = total_worlds * args.steps / elapsed
         steps_per_launch = args.steps / launches
         launch_ms = dev_ms / launches
-        balg = B_ALG[args.policy]
-        # the library's own rule (cagym_api.hip): M = 10 runs 4 worlds per workgroup while the launch is co-resident
-        cus = torch.cuda.get_device_properties(device).multi_processor_count
-        spec = {10: "256, 10, %d" % (4 if (N + 3) // 4 <= 5 * cus else 5), 4: "256, 4, 0", 20: "256, 20, 2"}
-        kernel_name = "%s<%s, true>" % ("k_step2" if args.per_step_launch else "k_rollout2",
-                                        spec.get(M, "256, 0, 0" if M <= 12 else "512, 0, 0"))
+        balg = B_STATE + (B_OAS9 if M <= 10 else B_OAS19)
+        kernel_name = env.kernel_name(rollout=not args.per_step_launch, auto_reset=True)
         achieved = balg * N * M * steps_per_launch / (launch_ms * 1e-3) / 1e9
-        # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate
-        # rocprofv3 --pmc passes; profiles/r1/bench_4096x10_rvo_pmc_hbm.txt): 418.5 B per agent-step at 512 steps per
-        # launch, 423.9 B at 64 (per-step outputs 417.7 B + 395 B of state in/out per agent and launch); measured on this
-        # workload only and not re-measured live, so null for any other shape.
+        # HBM bytes per launch from the PMC counters are NOT collected in this run (they need rocprofv3 --pmc passes);
+        # the figure below replays profiles/ (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes) for the
+        # headline shape only and is labelled as such; null for any other shape.
         traffic = None
         traffic_per_agent_step = 417.7 + 395.0 / steps_per_launch
-        if (N, M, args.policy, args.per_step_launch) == (4096, 10, "rvo", False):
+        if (N, M, policy, args.per_step_launch) == (4096, 10, "rvo", False):
             traffic = traffic_per_agent_step * N * M * steps_per_launch / (launch_ms * 1e-3) / 1e9  # GB/s, comparable to `achieved`
         # measured device-to-device copy ceiling next to the vendor HBM figure: read + write of 1 GiB
         src = torch.empty(1 << 30, dtype=torch.uint8, device=device)
@@ -197,16 +255,24 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%d worlds x %d agents per GPU, %s policy + OtherAgentsStates sensor, "
-                                   "UnicycleDynamics, random-goal episodes with auto-reset (BASELINE configs[2])"
-                                   % (N, M, "RVO/ORCA on-device LP" if args.policy == "rvo" else "NonCooperative"),
+                                   "UnicycleDynamics, random-goal episodes with auto-reset (BASELINE configs[%d])"
+                                   % (N, M, "RVO/ORCA on-device LP" if policy == "rvo" else "NonCooperative",
+                                      2 if args.config == "cfg3" else 1),
                        "worlds_per_gpu": N, "agents": M, "steps_per_launch": steps_per_launch,
-                       "launch_mode": "cagym_step per step" if args.per_step_launch else "cagym_rollout",
+                       "launch_mode": "cagym_step_autoreset per step" if args.per_step_launch else "cagym_rollout",
                        "parallelism": "worlds sharded x%d, no data-path collective" % world_size},
+            "repeats": len(blocks), "timing": "median of %d timed blocks of %d steps" % (len(blocks), args.steps),
+            "ms_per_step_min": 1e3 * walls[0] / args.steps, "ms_per_step_max": 1e3 * walls[-1] / args.steps,
+            "rccl_ranks": world_size if (world_size > 1 and backend == "nccl") else 0,
+            "collective_backend": backend if world_size > 1 else None,
             "agent_steps_per_s": value * M,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": None if traffic is None else
+                         "replayed from profiles/r2 PMC passes of this shape (FETCH_SIZE x2 + WRITE_SIZE per agent-step), not measured in this run",
                          "kernel": kernel_name,
-                         "launch_ms": launch_ms, "alg_bytes_per_agent_step": balg,
+                         "launch_ms": launch_ms, "launch_ms_min": dev_sorted[0] / launches, "launch_ms_max": dev_sorted[-1] / launches,
+                         "alg_bytes_per_agent_step": balg,
                          "measured_d2d_copy_GBs": copy_gbs,
                          "alg_bytes_per_launch": balg * N * M * steps_per_launch,
                          "traffic_bytes_per_launch": None if traffic is None else traffic_per_agent_step * N * M * steps_per_launch},
@@ -214,7 +280,7 @@ def main():
         }
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(M, pol)
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if world_size > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -50,7 +50,7 @@ class CagymScenarioPtrs(C.Structure):
 
 EXPORTS = ["cagym_version", "cagym_create", "cagym_destroy", "cagym_last_error", "cagym_set_scenarios",
            "cagym_reset", "cagym_step", "cagym_step_autoreset", "cagym_rollout", "cagym_get_state", "cagym_laserscan",
-           "cagym_generate_scenarios", "cagym_get_scenarios", "cagym_occupancy_grid"]
+           "cagym_generate_scenarios", "cagym_get_scenarios", "cagym_occupancy_grid", "cagym_kernel_name"]
 
 _lib = None
 
@@ -82,6 +82,7 @@ def load():
     L.cagym_occupancy_grid.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.cagym_generate_scenarios.argtypes = [C.c_void_p, C.POINTER(CagymGenParams), C.POINTER(C.c_int32), C.c_void_p]
     L.cagym_get_scenarios.argtypes = [C.c_void_p, C.POINTER(CagymScenarioPtrs)]
+    L.cagym_kernel_name.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_int]
     _lib = L
     return L
 

@@ -188,6 +188,13 @@ class BatchedCollisionAvoidanceEnv(object):
         _lib.check(self.L, self.h, rc, "cagym_rollout")
         return out
 
+    def kernel_name(self, rollout=True, auto_reset=True):
+        """The kernel instantiation the library launches for this handle (as rocprofv3 --kernel-trace names it)."""
+        buf = C.create_string_buffer(128)
+        _lib.check(self.L, self.h, self.L.cagym_kernel_name(self.h, int(bool(rollout)), int(bool(auto_reset)), buf, 128),
+                   "cagym_kernel_name")
+        return buf.value.decode()
+
     def sense_laserscan(self, out=None):
         if out is None:
             out = torch.empty((self.N, self.M, 16), dtype=torch.float32, device=self.device)

@@ -48,6 +48,27 @@ int fail(Env* e, int code, const std::string& msg) {
             return fail(e, CAGYM_E_HIP, std::string(#call) + ": " + hipGetErrorString(_s));          \
     } while (0)
 
+// Every launching entry point runs with the handle's device current (a C caller may hold handles on several devices:
+// "one process, 8 handles") and leaves the caller's current device as it found it.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    hipError_t status = hipSuccess;
+    explicit DeviceGuard(int dev) {
+        status = hipGetDevice(&prev);
+        if (status == hipSuccess && prev != dev) {
+            status = hipSetDevice(dev);
+            switched = status == hipSuccess;
+        }
+    }
+    ~DeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+};
+#define DEVGUARD(e)                                                                                        \
+    DeviceGuard _guard((e)->cfg.device);                                                                   \
+    if (_guard.status != hipSuccess) return fail(e, CAGYM_E_HIP, std::string("hipSetDevice: ") + hipGetErrorString(_guard.status))
+
 template <typename T>
 int dalloc(Env* e, T** p, size_t n) {
     void* q = nullptr;
@@ -86,10 +107,20 @@ CagymOut to_out(const cagym_outputs* o) {
 #ifndef NT20
 #define NT20 256  /* lanes per workgroup of the M = 20 specialisation (512: 64 vs 78 M env-steps/s at 2048 x 20) */
 #endif
-inline int wpw_spec(const Env* e) {
+// kernel specialisation of the handle: lanes per workgroup, compile-time M (0 = generic) and worlds per workgroup
+// (0 = 64 / M worlds, LDS stride 64)
+struct Spec2 {
+    int nt, mt, wpw;
+};
+inline Spec2 spec2(const Env* e) {
     const int M = e->cfg.max_agents;
-    return M == 10 ? e->wpw10 : (M == 20 ? WPW20 : 0);
+    if (M == 10) return {256, 10, e->wpw10};
+    if (M == 4) return {256, 4, 0};
+    if (M == 20) return {NT20, 20, WPW20};
+    if (M <= 12) return {256, 0, 0};
+    return {512, 0, 0};
 }
+inline int wpw_spec(const Env* e) { return spec2(e).wpw; }
 inline int n_wg2(const Env* e) {
     const int M = e->cfg.max_agents;
     const int wpw = wpw_spec(e) ? wpw_spec(e) : CAGYM_WAVE / M;
@@ -104,6 +135,26 @@ inline int n_waves(const Env* e) {
     int wpw = CAGYM_WAVE / e->cfg.max_agents;
     return (e->cfg.n_worlds + wpw - 1) / wpw;
 }
+
+template <int NT, int MT, int WP>
+void set_lds_attr2(int lds2) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<NT, MT, WP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<NT, MT, WP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<NT, MT, WP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<NT, MT, WP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+}
+
+// the one place that maps a handle to its generation-2 kernel instantiation
+#define CAGYM_DISPATCH2(e, CALL)                                   \
+    do {                                                           \
+        const Spec2 _s = spec2(e);                                 \
+        if (_s.mt == 10 && _s.wpw == 4) { CALL(256, 10, 4); }      \
+        else if (_s.mt == 10) { CALL(256, 10, 5); }                \
+        else if (_s.mt == 4) { CALL(256, 4, 0); }                  \
+        else if (_s.mt == 20) { CALL(NT20, 20, WPW20); }           \
+        else if (_s.nt == 256) { CALL(256, 0, 0); }                \
+        else { CALL(512, 0, 0); }                                  \
+    } while (0)
 
 }  // namespace
 
@@ -130,7 +181,11 @@ int cagym_create(const cagym_config* cfg, void** env_out) {
     if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, CAGYM_E_INVALID, "device ordinal out of range");
     Env* e = new Env();
     e->cfg = *cfg;
-    HIPCHK(e, hipSetDevice(cfg->device));
+    DeviceGuard guard(cfg->device);
+    if (guard.status != hipSuccess) {
+        delete e;
+        return fail(nullptr, CAGYM_E_HIP, std::string("hipSetDevice: ") + hipGetErrorString(guard.status));
+    }
     CagymDev& D = e->D;
     memset(&D, 0, sizeof(D));
     const size_t N = cfg->n_worlds, M = cfg->max_agents, S = cfg->n_scenarios, NM = N * M, SM = S * M;
@@ -183,34 +238,9 @@ int cagym_create(const cagym_config* cfg, void** env_out) {
         }
         int lds2 = (int)lds2_bytes(e);
         if (lds2 > 160 * 1024) e->generation = 1;
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<256, 0, 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<256, 10, 5, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<256, 10, 4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<256, 4, 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<NT20, 20, WPW20, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<256, 4, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<256, 4, 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<NT20, 20, WPW20, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<NT20, 20, WPW20, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<256, 10, 5, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<256, 10, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<256, 10, 5, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<256, 10, 4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<512, 0, 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<256, 0, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<256, 10, 5, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<256, 10, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<256, 4, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<NT20, 20, WPW20, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<512, 0, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<512, 0, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<512, 0, 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<256, 0, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<512, 0, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<512, 0, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<256, 0, 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<512, 0, 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<512, 0, 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+#define SETATTR(NT, MT, WP) set_lds_attr2<NT, MT, WP>(lds2)
+        CAGYM_DISPATCH2(e, SETATTR);
+#undef SETATTR
     }
     (void)hipGetLastError();
     *env_out = e;
@@ -233,7 +263,7 @@ int cagym_set_scenarios(void* env, const double* agents6, const double* heading0
     if (!e) return fail(nullptr, CAGYM_E_INVALID, "null env");
     if (!agents6 || !policy_id || !dynamics_id) return fail(e, CAGYM_E_INVALID, "agents6 / policy_id / dynamics_id are required");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    HIPCHK(e, hipSetDevice(e->cfg.device));
+    DEVGUARD(e);
     const size_t S = e->cfg.n_scenarios, M = e->cfg.max_agents, SM = S * M;
     // validate ids on the host: the kernels index switch tables with them
     for (size_t k = 0; k < SM; k++) {
@@ -297,7 +327,7 @@ int cagym_generate_scenarios(void* env, const cagym_gen_params* params, int32_t*
         return fail(e, CAGYM_E_INVALID, "dynamics id out of range");
     if (P.max_tries < 1 || !(P.side > 0) || !(P.p_b >= 0 && P.p_b <= 1)) return fail(e, CAGYM_E_INVALID, "bad generator parameters");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    HIPCHK(e, hipSetDevice(e->cfg.device));
+    DEVGUARD(e);
     CagymDev& D = e->D;
     GenDev G;
     G.agents6 = const_cast<double*>(D.sc_agents6);
@@ -344,6 +374,7 @@ int cagym_reset(void* env, const uint8_t* world_mask, int advance_episode, const
     Env* e = reinterpret_cast<Env*>(env);
     if (!e) return fail(nullptr, CAGYM_E_INVALID, "null env");
     if (!e->scenarios_set) return fail(e, CAGYM_E_STATE, "cagym_reset before cagym_set_scenarios");
+    DEVGUARD(e);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     CagymOut o = to_out(out);
     hipLaunchKernelGGL(k_reset, dim3(n_waves(e)), dim3(64), cagym_lds_bytes(e->cfg.max_agents), st, e->D, world_mask,
@@ -357,18 +388,14 @@ int cagym_step(void* env, const float* ext_actions, const cagym_outputs* out, vo
     Env* e = reinterpret_cast<Env*>(env);
     if (!e) return fail(nullptr, CAGYM_E_INVALID, "null env");
     if (!e->scenarios_set) return fail(e, CAGYM_E_STATE, "cagym_step before cagym_set_scenarios");
+    DEVGUARD(e);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     CagymOut o = to_out(out);
-    const int M = e->cfg.max_agents;
     if (e->generation == 2) {
         const size_t lds2 = lds2_bytes(e);
-        if (M == 10 && e->wpw10 == 4) hipLaunchKernelGGL((k_step2<256, 10, 4, false>), dim3(n_wg2(e)), dim3(256), lds2, st, e->D, ext_actions, o, e->any_rvo);
-        else if (M == 10) hipLaunchKernelGGL((k_step2<256, 10, 5, false>), dim3(n_wg2(e)), dim3(256), lds2, st, e->D, ext_actions, o, e->any_rvo);
-        else if (M == 4) hipLaunchKernelGGL((k_step2<256, 4, 0, false>), dim3(n_wg2(e)), dim3(256), lds2, st, e->D, ext_actions, o, e->any_rvo);
-        else if (M == 20) hipLaunchKernelGGL((k_step2<NT20, 20, WPW20, false>), dim3(n_wg2(e)), dim3(NT20), lds2, st, e->D, ext_actions, o, e->any_rvo);
-        else if (M <= 12) hipLaunchKernelGGL((k_step2<256, 0, 0, false>), dim3(n_waves(e)), dim3(256), lds2, st, e->D, ext_actions, o, e->any_rvo);
-        else if (M <= 16) hipLaunchKernelGGL((k_step2<512, 0, 0, false>), dim3(n_waves(e)), dim3(512), lds2, st, e->D, ext_actions, o, e->any_rvo);
-        else hipLaunchKernelGGL((k_step2<512, 0, 0, false>), dim3(n_waves(e)), dim3(512), lds2, st, e->D, ext_actions, o, e->any_rvo);
+#define STEP2(NT, MT, WP) hipLaunchKernelGGL((k_step2<NT, MT, WP, false>), dim3(n_wg2(e)), dim3(NT), lds2, st, e->D, ext_actions, o, e->any_rvo)
+        CAGYM_DISPATCH2(e, STEP2);
+#undef STEP2
     } else
     hipLaunchKernelGGL(k_step, dim3(n_waves(e)), dim3(64), cagym_lds_bytes(e->cfg.max_agents), st, e->D, ext_actions, o);
     HIPCHK(e, hipGetLastError());
@@ -380,18 +407,14 @@ int cagym_step_autoreset(void* env, const float* ext_actions, const cagym_output
     Env* e = reinterpret_cast<Env*>(env);
     if (!e) return fail(nullptr, CAGYM_E_INVALID, "null env");
     if (!e->scenarios_set) return fail(e, CAGYM_E_STATE, "cagym_step_autoreset before cagym_set_scenarios");
+    DEVGUARD(e);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     CagymOut o = to_out(out);
-    const int M = e->cfg.max_agents;
     if (e->generation == 2) {
         const size_t lds2 = lds2_bytes(e);
-        if (M == 10 && e->wpw10 == 4) hipLaunchKernelGGL((k_step2<256, 10, 4, true>), dim3(n_wg2(e)), dim3(256), lds2, st, e->D, ext_actions, o, e->any_rvo);
-        else if (M == 10) hipLaunchKernelGGL((k_step2<256, 10, 5, true>), dim3(n_wg2(e)), dim3(256), lds2, st, e->D, ext_actions, o, e->any_rvo);
-        else if (M == 4) hipLaunchKernelGGL((k_step2<256, 4, 0, true>), dim3(n_wg2(e)), dim3(256), lds2, st, e->D, ext_actions, o, e->any_rvo);
-        else if (M == 20) hipLaunchKernelGGL((k_step2<NT20, 20, WPW20, true>), dim3(n_wg2(e)), dim3(NT20), lds2, st, e->D, ext_actions, o, e->any_rvo);
-        else if (M <= 12) hipLaunchKernelGGL((k_step2<256, 0, 0, true>), dim3(n_waves(e)), dim3(256), lds2, st, e->D, ext_actions, o, e->any_rvo);
-        else if (M <= 16) hipLaunchKernelGGL((k_step2<512, 0, 0, true>), dim3(n_waves(e)), dim3(512), lds2, st, e->D, ext_actions, o, e->any_rvo);
-        else hipLaunchKernelGGL((k_step2<512, 0, 0, true>), dim3(n_waves(e)), dim3(512), lds2, st, e->D, ext_actions, o, e->any_rvo);
+#define STEP2(NT, MT, WP) hipLaunchKernelGGL((k_step2<NT, MT, WP, true>), dim3(n_wg2(e)), dim3(NT), lds2, st, e->D, ext_actions, o, e->any_rvo)
+        CAGYM_DISPATCH2(e, STEP2);
+#undef STEP2
     } else
         return fail(e, CAGYM_E_UNSUPPORTED, "cagym_step_autoreset needs the generation-2 kernels");
     HIPCHK(e, hipGetLastError());
@@ -403,13 +426,13 @@ int cagym_rollout(void* env, int n_steps, int auto_reset, const cagym_outputs* o
     Env* e = reinterpret_cast<Env*>(env);
     if (!e) return fail(nullptr, CAGYM_E_INVALID, "null env");
     if (!e->scenarios_set) return fail(e, CAGYM_E_STATE, "cagym_rollout before cagym_set_scenarios");
+    DEVGUARD(e);
     if (n_steps < 1) return fail(e, CAGYM_E_INVALID, "n_steps must be >= 1");
     if (e->cfg.laserscan && out && out->laserscan)
         return fail(e, CAGYM_E_UNSUPPORTED, "cagym_rollout does not produce laserscan (use cagym_step)");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     CagymOut o = to_out(out);
     size_t lds = cagym_lds_bytes(e->cfg.max_agents);
-    const int M = e->cfg.max_agents;
     if (e->generation == 2) {
         const size_t lds2 = lds2_bytes(e);
         const dim3 g(n_wg2(e));
@@ -418,12 +441,7 @@ int cagym_rollout(void* env, int n_steps, int auto_reset, const cagym_outputs* o
         if (auto_reset) hipLaunchKernelGGL((k_rollout2<NT, MT, WP, true>), g, dim3(NT), lds2, st, e->D, n_steps, o, e->any_rvo); \
         else hipLaunchKernelGGL((k_rollout2<NT, MT, WP, false>), g, dim3(NT), lds2, st, e->D, n_steps, o, e->any_rvo);         \
     } while (0)
-        if (M == 10 && e->wpw10 == 4) ROLL2(256, 10, 4);
-        else if (M == 10) ROLL2(256, 10, 5);
-        else if (M == 4) ROLL2(256, 4, 0);
-        else if (M == 20) ROLL2(NT20, 20, WPW20);
-        else if (M <= 12) ROLL2(256, 0, 0);
-        else ROLL2(512, 0, 0);
+        CAGYM_DISPATCH2(e, ROLL2);
 #undef ROLL2
     } else if (auto_reset)
         hipLaunchKernelGGL(k_rollout<true>, dim3(n_waves(e)), dim3(64), lds, st, e->D, n_steps, o);
@@ -433,10 +451,26 @@ int cagym_rollout(void* env, int n_steps, int auto_reset, const cagym_outputs* o
     return CAGYM_OK;
 }
 
+int cagym_kernel_name(void* env, int rollout, int auto_reset, char* buf, int buf_len) {
+    Env* e = reinterpret_cast<Env*>(env);
+    if (!e || !buf || buf_len < 1) return fail(e, CAGYM_E_INVALID, "bad arguments");
+    if (e->generation == 2) {
+        const Spec2 sp = spec2(e);
+        snprintf(buf, (size_t)buf_len, "%s<%d, %d, %d, %s>", rollout ? "k_rollout2" : "k_step2", sp.nt, sp.mt, sp.wpw,
+                 auto_reset ? "true" : "false");
+    } else if (rollout) {
+        snprintf(buf, (size_t)buf_len, "k_rollout<%s>", auto_reset ? "true" : "false");
+    } else {
+        snprintf(buf, (size_t)buf_len, "k_step");
+    }
+    return CAGYM_OK;
+}
+
 int cagym_laserscan(void* env, float* laserscan, void* stream) {
     Env* e = reinterpret_cast<Env*>(env);
     if (!e) return fail(nullptr, CAGYM_E_INVALID, "null env");
     if (!laserscan) return fail(e, CAGYM_E_INVALID, "null laserscan buffer");
+    DEVGUARD(e);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     size_t total = (size_t)e->cfg.n_worlds * e->cfg.max_agents * 16;
     hipLaunchKernelGGL(k_laserscan, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, e->D, laserscan);
@@ -449,6 +483,7 @@ int cagym_occupancy_grid(void* env, uint8_t* grid, void* stream) {
     if (!e) return fail(nullptr, CAGYM_E_INVALID, "null env");
     if (!grid) return fail(e, CAGYM_E_INVALID, "null grid buffer");
     if (e->cfg.max_obstacles <= 0) return fail(e, CAGYM_E_STATE, "cagym_occupancy_grid needs an env created with max_obstacles > 0");
+    DEVGUARD(e);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(k_occupancy_grid, dim3((unsigned)((size_t)e->cfg.n_worlds * e->cfg.max_agents)), dim3(256), 0, st, e->D, grid);
     HIPCHK(e, hipGetLastError());
@@ -474,6 +509,7 @@ int cagym_ga3c_state(void* env, int max_observed, float* state, void* stream) {
     Env* e = reinterpret_cast<Env*>(env);
     if (!e) return fail(nullptr, CAGYM_E_INVALID, "null env");
     if (!state || max_observed < 1 || max_observed > 10) return fail(e, CAGYM_E_INVALID, "bad arguments (max_observed in 1..10)");
+    DEVGUARD(e);
     size_t total = (size_t)e->cfg.n_worlds * e->cfg.max_agents;
     hipLaunchKernelGGL(k_ga3c_state, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), e->D, max_observed, state);
@@ -492,12 +528,20 @@ int cagym_debug_stamps(unsigned long long* out16, int reset) {
 }
 #endif
 
+#ifdef CAGYM_WGTRACE
+int cagym_debug_wgtrace(unsigned long long* out, int n_wg) {
+    if (n_wg > CAGYM_WGTRACE_MAXWG) n_wg = CAGYM_WGTRACE_MAXWG;
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wgtrace), sizeof(unsigned long long) * CAGYM_WGTRACE_W * (size_t)n_wg);
+}
+#endif
+
 int cagym_ga3c_forward(void* env, const float* weights, const float* state, const int32_t* agent_idx, int B,
                        float* ext_actions, int32_t* action_index, float* probs, void* stream) {
     Env* e = reinterpret_cast<Env*>(env);
     if (!e) return fail(nullptr, CAGYM_E_INVALID, "null env");
     if (!weights || !state || !agent_idx || B < 0) return fail(e, CAGYM_E_INVALID, "bad arguments");
     if (B == 0) return CAGYM_OK;
+    DEVGUARD(e);
     // 32 agents per workgroup reuse every weight 32 times; small batches take 16 so that each CU still gets >= 2 workgroups
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (B <= 16 * 1024)
@@ -524,7 +568,7 @@ int cagym_ig_init(void* env, void* stream) {
     if (e->cfg.max_obstacles <= 0 || !e->D.map_bits)
         return fail(e, CAGYM_E_UNSUPPORTED, "information-gain primitives need obstacle rasters (max_obstacles > 0)");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    HIPCHK(e, hipSetDevice(e->cfg.device));
+    DEVGUARD(e);
     const size_t S = e->cfg.n_scenarios, N = e->cfg.n_worlds;
     if (!e->G.d2) {
         int rc;
@@ -546,6 +590,7 @@ int cagym_ig_reset_belief(void* env, const uint8_t* world_mask, void* stream) {
     Env* e = reinterpret_cast<Env*>(env);
     int rc = ig_check(e, "cagym_ig_reset_belief");
     if (rc) return rc;
+    DEVGUARD(e);
     hipLaunchKernelGGL(k_ig_fill_belief, dim3((unsigned)e->cfg.n_worlds), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), e->G, world_mask);
     HIPCHK(e, hipGetLastError());
@@ -556,6 +601,7 @@ int cagym_ig_get(void* env, uint32_t** edf_d2, double** belief) {
     Env* e = reinterpret_cast<Env*>(env);
     int rc = ig_check(e, "cagym_ig_get");
     if (rc) return rc;
+    DEVGUARD(e);
     if (edf_d2) *edf_d2 = e->G.d2;
     if (belief) *belief = e->G.belief;
     return CAGYM_OK;
@@ -566,6 +612,7 @@ int cagym_ig_visible_cells(void* env, const double* poses, const int32_t* world,
     Env* e = reinterpret_cast<Env*>(env);
     int rc = ig_check(e, "cagym_ig_visible_cells");
     if (rc) return rc;
+    DEVGUARD(e);
     if (Q < 0 || !poses || !world || !masks) return fail(e, CAGYM_E_INVALID, "bad arguments");
     if (Q == 0) return CAGYM_OK;
     hipLaunchKernelGGL(k_ig_visible, dim3((unsigned)Q), dim3(128), 0, reinterpret_cast<hipStream_t>(stream), e->G, poses,
@@ -580,6 +627,7 @@ int cagym_ig_update_belief(void* env, const double* poses, const int32_t* n_pose
     Env* e = reinterpret_cast<Env*>(env);
     int rc = ig_check(e, "cagym_ig_update_belief");
     if (rc) return rc;
+    DEVGUARD(e);
     if (P < 1 || Dmax < 1 || !poses || !detections || !n_det) return fail(e, CAGYM_E_INVALID, "bad arguments");
     hipLaunchKernelGGL(k_ig_update, dim3((unsigned)e->cfg.n_worlds), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        e->G, poses, n_poses, detections, n_det, P, Dmax, fov_rad, range,
@@ -592,6 +640,7 @@ int cagym_ig_mi_reward(void* env, const uint64_t* masks, const int32_t* world, i
     Env* e = reinterpret_cast<Env*>(env);
     int rc = ig_check(e, "cagym_ig_mi_reward");
     if (rc) return rc;
+    DEVGUARD(e);
     if (Q < 0 || !masks || !world || !reward) return fail(e, CAGYM_E_INVALID, "bad arguments");
     if (Q == 0) return CAGYM_OK;
     hipLaunchKernelGGL(k_ig_reward, dim3((unsigned)Q), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), e->G,
@@ -605,6 +654,7 @@ int cagym_ig_next_pose(void* env, const double* poses, const double* actions, co
     Env* e = reinterpret_cast<Env*>(env);
     int rc = ig_check(e, "cagym_ig_next_pose");
     if (rc) return rc;
+    DEVGUARD(e);
     if (Q < 0 || xdt < 1 || xdt > 1000 || !poses || !actions || !world || !radius || !next || !feasible)
         return fail(e, CAGYM_E_INVALID, "bad arguments");
     if (Q == 0) return CAGYM_OK;
@@ -622,6 +672,7 @@ int cagym_ig_rollouts(void* env, const double* pose0, const uint64_t* observed0,
     Env* e = reinterpret_cast<Env*>(env);
     int rc = ig_check(e, "cagym_ig_rollouts");
     if (rc) return rc;
+    DEVGUARD(e);
     if (Q < 0 || nsims < 1 || max_steps < 0 || max_steps > 255 || xdt < 1 || xdt > 1000 || !pose0 || !observed0 ||
         !exclude || !world || !n_steps || !radius || !rewards)
         return fail(e, CAGYM_E_INVALID, "bad arguments");
@@ -652,6 +703,7 @@ int cagym_dmcts_plan(void* env, const cagym_dmcts_params* params, const double* 
     Env* e = reinterpret_cast<Env*>(env);
     int rc = ig_check(e, "cagym_dmcts_plan");
     if (rc) return rc;
+    DEVGUARD(e);
     if (!params || !poses || !workspace || !actions || !paths || !stats) return fail(e, CAGYM_E_INVALID, "null argument");
     const cagym_dmcts_params& p = *params;
     if (p.n_robots < 1 || p.n_robots > DM_MAXR || p.horizon < 1 || p.horizon > DM_MAXH || p.Nsims < 1 || p.Nsims > DM_MAXSIMS ||

@@ -35,6 +35,28 @@ __device__ unsigned long long g_stamps[16];
 #define STAMP_BEGIN() do { } while (0)
 #endif
 
+// Second diagnostic build (-DCAGYM_WGTRACE, tools/launch_cost.py): thread 0 of EVERY workgroup records the 100 MHz
+// s_memrealtime clock at kernel entry, after the prologue, after each of the first 36 steps and at exit, plus its XCC id,
+// into g_wgtrace (read back with cagym_debug_wgtrace()).  Same rule: the values feed no output.
+#ifdef CAGYM_WGTRACE
+#define CAGYM_WGTRACE_MAXWG 4096
+#define CAGYM_WGTRACE_W 40
+__device__ unsigned long long g_wgtrace[CAGYM_WGTRACE_MAXWG * CAGYM_WGTRACE_W];
+#define WGTRACE(slot)                                                                                       \
+    do {                                                                                                    \
+        if (threadIdx.x == 0 && blockIdx.x < CAGYM_WGTRACE_MAXWG && (slot) < CAGYM_WGTRACE_W)               \
+            g_wgtrace[blockIdx.x * CAGYM_WGTRACE_W + (slot)] = __builtin_amdgcn_s_memrealtime();            \
+    } while (0)
+#define WGTRACE_BUSY(cnt)                                                                                   \
+    do {                                                                                                    \
+        if (threadIdx.x == 0 && blockIdx.x < CAGYM_WGTRACE_MAXWG)                                           \
+            g_wgtrace[blockIdx.x * CAGYM_WGTRACE_W + 39] += (unsigned long long)(cnt) << 8;                 \
+    } while (0)
+#else
+#define WGTRACE(slot) do { } while (0)
+#define WGTRACE_BUSY(cnt) do { } while (0)
+#endif
+
 #ifndef CAGYM_GW10
 #define CAGYM_GW10 8  // lanes per ORCA LP group when M <= 10 (nn <= 9 half-planes)
 #endif
@@ -326,6 +348,7 @@ __device__ inline void step_core2(const CagymDev& D, const Lds2& W, LaneCtx& C, 
             cnt = __popcll(bm);
             if (fl) W.lpk[__popcll(bm & ((1ull << lane) - 1ull))] = lane;
         }
+        WGTRACE_BUSY(cnt);
         const int g = tid / GW, j = tid & (GW - 1);
         // busy egos are packed into as few waves as possible (dealing them round-robin over the waves was slower at
         // every launch size: 301 vs 312 M env-steps/s at 4096 worlds, 507 vs 521 M at 65536)
@@ -652,6 +675,10 @@ __device__ inline void step_core2(const CagymDev& D, const Lds2& W, LaneCtx& C, 
 template <int NT, int MT, int WPWT, bool AUTO_RESET>
 __global__ void __launch_bounds__(NT, (NT <= 256 ? 3 : 2)) k_rollout2(CagymDev D, int n_steps, CagymOut out, int any_rvo) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    WGTRACE(0);
+#ifdef CAGYM_WGTRACE
+    if (threadIdx.x == 0 && blockIdx.x < CAGYM_WGTRACE_MAXWG) g_wgtrace[blockIdx.x * CAGYM_WGTRACE_W + 39] = 0;
+#endif
     const int M = MT ? MT : D.M;
     Lds2 W = carve_lds2(smem, M, cagym_as(M, WPWT));
     LaneCtx C = make_ctx2(D, M, WPWT ? WPWT : CAGYM_WAVE / M);
@@ -670,6 +697,7 @@ __global__ void __launch_bounds__(NT, (NT <= 256 ? 3 : 2)) k_rollout2(CagymDev D
         if (C.wl < C.wpw && C.slot == 0) W.wn[C.wl] = C.valid ? C.n : 0;
         publish_pref_velocity(W, threadIdx.x);
     }
+    WGTRACE(1);
     const size_t NM = (size_t)D.N * M;
 #pragma nounroll
     for (int t = 0; t < n_steps; t++) {
@@ -681,6 +709,7 @@ __global__ void __launch_bounds__(NT, (NT <= 256 ? 3 : 2)) k_rollout2(CagymDev D
         o.flags = out.flags ? out.flags + (size_t)t * NM : nullptr;
         o.game_over = out.game_over ? out.game_over + (size_t)t * D.N : nullptr;
         step_core2<NT, MT, WPWT, AUTO_RESET>(D, W, C, nullptr, o, ep_ret, ep_len, any_rvo != 0);
+        WGTRACE(2 + t);
     }
     if (C.valid) {
         const Agent A = lds_load_agent(W, threadIdx.x);  // own lane's record: no barrier needed
@@ -692,6 +721,11 @@ __global__ void __launch_bounds__(NT, (NT <= 256 ? 3 : 2)) k_rollout2(CagymDev D
             D.n_agents[C.world] = C.n;
         }
     }
+#ifdef CAGYM_WGTRACE
+    WGTRACE(38);
+    if (threadIdx.x == 0 && blockIdx.x < CAGYM_WGTRACE_MAXWG)
+        g_wgtrace[blockIdx.x * CAGYM_WGTRACE_W + 39] |= __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) & 15u;  // HW_REG_XCC_ID
+#endif
 }
 
 template <int NT, int MT, int WPWT, bool AUTO_RESET>

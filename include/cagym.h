@@ -58,7 +58,7 @@ enum { CAGYM_FLAG_AT_GOAL = 1, CAGYM_FLAG_IN_COLLISION = 2, CAGYM_FLAG_RAN_OUT_O
 /* Replaces the class attributes of envs/config.py read by the hot path. */
 typedef struct {
     int32_t n_worlds;            /* N: worlds stepped together (one reference env instance each)            */
-    int32_t max_agents;          /* M: Config.MAX_NUM_AGENTS_IN_ENVIRONMENT (config.py:70); 2..64           */
+    int32_t max_agents;          /* M: Config.MAX_NUM_AGENTS_IN_ENVIRONMENT (config.py:70); 2..32           */
     int32_t n_scenarios;         /* S >= N: scenario pool; world w starts episode e on scenario (w+e*N)%S   */
     int32_t max_obstacles;       /* rectangles per scenario (0 = free space; env.py:492-497)                */
     int32_t game_over_mode;      /* CAGYM_GO_*                                                              */
@@ -142,6 +142,10 @@ int cagym_step_autoreset(void* env, const float* ext_actions, const cagym_output
 int cagym_rollout(void* env, int n_steps, int auto_reset, const cagym_outputs* out, void* stream);
 
 int cagym_get_state(void* env, cagym_state_ptrs* out);
+
+/* Name of the kernel instantiation this handle launches for cagym_step / cagym_step_autoreset (rollout == 0) or
+ * cagym_rollout (rollout != 0), as rocprofv3 --kernel-trace prints it (bench.py reports it next to the roofline). */
+int cagym_kernel_name(void* env, int rollout, int auto_reset, char* buf, int buf_len);
 
 /* LaserScanSensor.sense (sensors/LaserScanSensor.py:27-58) on the current state -> laserscan [N,M,16]. */
 int cagym_laserscan(void* env, float* laserscan, void* stream);

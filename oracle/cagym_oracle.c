@@ -12,6 +12,9 @@
 #include <stdlib.h>
 #include <string.h>
 #include <float.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #define MAPD 300 /* int(30/0.1), Map.py:18 */
 #define NBEAM 16 /* Config.LASERSCAN_LENGTH, config.py:57 */
@@ -380,13 +383,17 @@ static int lp2(const orca_line* L, int n, float radius, float ox, float oy, int 
     return n;
 }
 
-static void lp3(const orca_line* L, int n, int begin, float radius, float* rx, float* ry) {
+/* linearProgram3(lines, numObstLines, beginLine, radius, result): the obstacle lines [0, num_obst) are hard
+ * constraints, copied unprojected in front of the projected agent lines */
+#define CAO_MAXLINES 192 /* 2 visible edges per rectangle x 64 rectangles + 63 neighbours, rounded */
+static void lp3(const orca_line* L, int n, int num_obst, int begin, float radius, float* rx, float* ry) {
     float distance = 0.0f;
-    orca_line P[64];
+    orca_line P[CAO_MAXLINES];
     for (int i = begin; i < n; i++) {
         if (detf(L[i].dx, L[i].dy, L[i].px - *rx, L[i].py - *ry) > distance) {
             int np = 0;
-            for (int j = 0; j < i; j++) {
+            for (int j = 0; j < num_obst; j++) P[np++] = L[j];
+            for (int j = num_obst; j < i; j++) {
                 orca_line ln;
                 float d = detf(L[i].dx, L[i].dy, L[j].dx, L[j].dy);
                 if (fabsf(d) <= RVO_EPS) {
@@ -410,14 +417,224 @@ static void lp3(const orca_line* L, int n, int begin, float radius, float* rx, f
     }
 }
 
+/* ---- static obstacles in the ORCA solve ------------------------------------------------------------------------
+ * RVOPolicy.find_next_action hands the world's rectangles to its private simulator (policies/RVOPolicy.py:56-57
+ * sim.addObstacle, :45 sim.processObstacles at the first call only - later re-additions never reach the obstacle tree,
+ * SURVEY Q21), timeHorizonObst = RVO_TIME_HORIZON (:25-28).  The arithmetic is RVO2 v2.0's (library absent: PARITY
+ * UNPINNED, restated from the published algorithm): RVOSimulator::addObstacle (unit directions, convexity),
+ * Agent::computeNeighbors / KdTree::queryObstacleTreeRecursive / Agent::insertObstacleNeighbor (an edge is a
+ * neighbour when the agent is strictly on its right side and closer than timeHorizonObst * maxSpeed + radius;
+ * nearest first) and the obstacle half of Agent::computeNewVelocity.
+ * Stated deviation: RVO2 stores the edges in a BSP tree whose construction may SPLIT an edge that straddles the
+ * supporting line of another edge (two collinear halves describing the same wall) and whose traversal fixes the order
+ * of equidistant neighbours; here edges are never split and equidistant edges keep (rectangle, edge) index order -
+ * the order RVO2 itself produces for a single rectangle.
+ * A rectangle (xl, yl, xu, yu) is the counter-clockwise polygon [(xu,yu), (xl,yu), (xl,yl), (xu,yl)] of
+ * test_cases.py:2496; Cython narrows the vertices to float. */
+typedef struct { float x, y, ux, uy; int convex; } orca_vertex;
+
+static void orca_rect_vertices(const double* rect, orca_vertex* V) {
+    const float xl = (float)rect[0], yl = (float)rect[1], xu = (float)rect[2], yu = (float)rect[3];
+    const float X[4] = {xu, xl, xl, xu}, Y[4] = {yu, yu, yl, yl};
+    for (int k = 0; k < 4; k++) {
+        const int nx = (k + 1) & 3, pv = (k + 3) & 3;
+        const float ex = X[nx] - X[k], ey = Y[nx] - Y[k];
+        const float inv = 1.0f / sqrtf(ex * ex + ey * ey); /* normalize(): Vector2 / abs */
+        V[k].x = X[k]; V[k].y = Y[k];
+        V[k].ux = ex * inv; V[k].uy = ey * inv;
+        /* isConvex_ = leftOf(prev, this, next) >= 0;  leftOf(a, b, c) = det(a - c, b - a) */
+        V[k].convex = detf(X[pv] - X[nx], Y[pv] - Y[nx], X[k] - X[pv], Y[k] - Y[pv]) >= 0.0f;
+    }
+}
+
+/* distSqPointLineSegment(a, b, c) */
+static float dist_sq_point_segment(float ax, float ay, float bx, float by, float cx, float cy) {
+    const float r = ((cx - ax) * (bx - ax) + (cy - ay) * (by - ay)) / ((bx - ax) * (bx - ax) + (by - ay) * (by - ay));
+    if (r < 0.0f) return (cx - ax) * (cx - ax) + (cy - ay) * (cy - ay);
+    if (r > 1.0f) return (cx - bx) * (cx - bx) + (cy - by) * (cy - by);
+    const float qx = cx - (ax + r * (bx - ax)), qy = cy - (ay + r * (by - ay));
+    return qx * qx + qy * qy;
+}
+
+/* One obstacle edge (vertex o1 -> its successor o2; pv = predecessor of o1) against the lines built so far.
+ * Returns 1 and fills *out when the edge contributes a half-plane. */
+static int orca_obstacle_line(const orca_vertex* o1, const orca_vertex* o2, const orca_vertex* pv, const orca_vertex* nx2,
+                              float px, float py, float vx, float vy, float radius, float inv_tho,
+                              const orca_line* L, int nl, orca_line* out) {
+    (void)nx2;
+    const float rp1x = o1->x - px, rp1y = o1->y - py, rp2x = o2->x - px, rp2y = o2->y - py;
+    /* already covered by an earlier obstacle line? */
+    for (int j = 0; j < nl; j++) {
+        if (detf(inv_tho * rp1x - L[j].px, inv_tho * rp1y - L[j].py, L[j].dx, L[j].dy) - inv_tho * radius >= -RVO_EPS &&
+            detf(inv_tho * rp2x - L[j].px, inv_tho * rp2y - L[j].py, L[j].dx, L[j].dy) - inv_tho * radius >= -RVO_EPS)
+            return 0;
+    }
+    const float dsq1 = rp1x * rp1x + rp1y * rp1y, dsq2 = rp2x * rp2x + rp2y * rp2y;
+    const float rsq = radius * radius;
+    const float ovx = o2->x - o1->x, ovy = o2->y - o1->y;
+    const float s = ((-rp1x) * ovx + (-rp1y) * ovy) / (ovx * ovx + ovy * ovy);
+    const float lx = -rp1x - s * ovx, ly = -rp1y - s * ovy;
+    const float dsq_line = lx * lx + ly * ly;
+    orca_line ln;
+    if (s < 0.0f && dsq1 <= rsq) { /* collision with the left vertex; ignored when non-convex */
+        if (!o1->convex) return 0;
+        const float nxv = -rp1y, nyv = rp1x, inv = 1.0f / sqrtf(nxv * nxv + nyv * nyv);
+        ln.px = 0.0f; ln.py = 0.0f; ln.dx = nxv * inv; ln.dy = nyv * inv;
+        *out = ln;
+        return 1;
+    } else if (s > 1.0f && dsq2 <= rsq) { /* collision with the right vertex; the neighbouring edge takes it otherwise */
+        if (!(o2->convex && detf(rp2x, rp2y, o2->ux, o2->uy) >= 0.0f)) return 0;
+        const float nxv = -rp2y, nyv = rp2x, inv = 1.0f / sqrtf(nxv * nxv + nyv * nyv);
+        ln.px = 0.0f; ln.py = 0.0f; ln.dx = nxv * inv; ln.dy = nyv * inv;
+        *out = ln;
+        return 1;
+    } else if (s >= 0.0f && s < 1.0f && dsq_line <= rsq) { /* collision with the segment */
+        ln.px = 0.0f; ln.py = 0.0f; ln.dx = -o1->ux; ln.dy = -o1->uy;
+        *out = ln;
+        return 1;
+    }
+    /* no collision: legs */
+    float llx, lly, rlx, rly; /* left / right leg direction */
+    const orca_vertex *a1 = o1, *a2 = o2; /* obstacle1 / obstacle2 after the oblique-view substitutions */
+    const orca_vertex* left_nb = pv;       /* obstacle1->prevObstacle_ */
+    if (s < 0.0f && dsq_line <= rsq) { /* viewed obliquely: the left vertex defines the velocity obstacle */
+        if (!o1->convex) return 0;
+        a2 = o1;
+        const float leg1 = sqrtf(dsq1 - rsq);
+        llx = (rp1x * leg1 - rp1y * radius) / dsq1; lly = (rp1x * radius + rp1y * leg1) / dsq1;
+        rlx = (rp1x * leg1 + rp1y * radius) / dsq1; rly = (-rp1x * radius + rp1y * leg1) / dsq1;
+    } else if (s > 1.0f && dsq_line <= rsq) { /* viewed obliquely: the right vertex defines it */
+        if (!o2->convex) return 0;
+        a1 = o2;
+        left_nb = o1; /* obstacle2->prevObstacle_ */
+        const float leg2 = sqrtf(dsq2 - rsq);
+        llx = (rp2x * leg2 - rp2y * radius) / dsq2; lly = (rp2x * radius + rp2y * leg2) / dsq2;
+        rlx = (rp2x * leg2 + rp2y * radius) / dsq2; rly = (-rp2x * radius + rp2y * leg2) / dsq2;
+    } else { /* usual situation */
+        if (o1->convex) {
+            const float leg1 = sqrtf(dsq1 - rsq);
+            llx = (rp1x * leg1 - rp1y * radius) / dsq1; lly = (rp1x * radius + rp1y * leg1) / dsq1;
+        } else { llx = -o1->ux; lly = -o1->uy; }
+        if (o2->convex) {
+            const float leg2 = sqrtf(dsq2 - rsq);
+            rlx = (rp2x * leg2 + rp2y * radius) / dsq2; rly = (-rp2x * radius + rp2y * leg2) / dsq2;
+        } else { rlx = o1->ux; rly = o1->uy; }
+    }
+    /* legs never point into a neighbouring edge of a convex vertex: the neighbour's cut-off line takes over */
+    int left_foreign = 0, right_foreign = 0;
+    if (a1->convex && detf(llx, lly, -left_nb->ux, -left_nb->uy) >= 0.0f) {
+        llx = -left_nb->ux; lly = -left_nb->uy;
+        left_foreign = 1;
+    }
+    if (a2->convex && detf(rlx, rly, a2->ux, a2->uy) <= 0.0f) {
+        rlx = a2->ux; rly = a2->uy;
+        right_foreign = 1;
+    }
+    /* cut-off centres */
+    const float lcx = inv_tho * (a1->x - px), lcy = inv_tho * (a1->y - py);
+    const float rcx = inv_tho * (a2->x - px), rcy = inv_tho * (a2->y - py);
+    const float cvx = rcx - lcx, cvy = rcy - lcy;
+    const int same = a1 == a2;
+    const float t = same ? 0.5f : ((vx - lcx) * cvx + (vy - lcy) * cvy) / (cvx * cvx + cvy * cvy);
+    const float t_left = (vx - lcx) * llx + (vy - lcy) * lly;
+    const float t_right = (vx - rcx) * rlx + (vy - rcy) * rly;
+    if ((t < 0.0f && t_left < 0.0f) || (same && t_left < 0.0f && t_right < 0.0f)) { /* left cut-off circle */
+        const float wx = vx - lcx, wy = vy - lcy, inv = 1.0f / sqrtf(wx * wx + wy * wy);
+        const float uwx = wx * inv, uwy = wy * inv;
+        ln.dx = uwy; ln.dy = -uwx;
+        ln.px = lcx + radius * inv_tho * uwx; ln.py = lcy + radius * inv_tho * uwy;
+        *out = ln;
+        return 1;
+    } else if (t > 1.0f && t_right < 0.0f) { /* right cut-off circle */
+        const float wx = vx - rcx, wy = vy - rcy, inv = 1.0f / sqrtf(wx * wx + wy * wy);
+        const float uwx = wx * inv, uwy = wy * inv;
+        ln.dx = uwy; ln.dy = -uwx;
+        ln.px = rcx + radius * inv_tho * uwx; ln.py = rcy + radius * inv_tho * uwy;
+        *out = ln;
+        return 1;
+    }
+    /* left leg, right leg or cut-off line, whichever is closest to the velocity */
+    float dc = INFINITY, dl = INFINITY, dr = INFINITY;
+    if (!(t < 0.0f || t > 1.0f || same)) {
+        const float qx = vx - (lcx + t * cvx), qy = vy - (lcy + t * cvy);
+        dc = qx * qx + qy * qy;
+    }
+    if (!(t_left < 0.0f)) {
+        const float qx = vx - (lcx + t_left * llx), qy = vy - (lcy + t_left * lly);
+        dl = qx * qx + qy * qy;
+    }
+    if (!(t_right < 0.0f)) {
+        const float qx = vx - (rcx + t_right * rlx), qy = vy - (rcy + t_right * rly);
+        dr = qx * qx + qy * qy;
+    }
+    if (dc <= dl && dc <= dr) { /* cut-off line */
+        ln.dx = -a1->ux; ln.dy = -a1->uy;
+        ln.px = lcx + radius * inv_tho * (-ln.dy); ln.py = lcy + radius * inv_tho * ln.dx;
+        *out = ln;
+        return 1;
+    } else if (dl <= dr) { /* left leg */
+        if (left_foreign) return 0;
+        ln.dx = llx; ln.dy = lly;
+        ln.px = lcx + radius * inv_tho * (-ln.dy); ln.py = lcy + radius * inv_tho * ln.dx;
+        *out = ln;
+        return 1;
+    }
+    if (right_foreign) return 0; /* right leg */
+    ln.dx = -rlx; ln.dy = -rly;
+    ln.px = rcx + radius * inv_tho * (-ln.dy); ln.py = rcy + radius * inv_tho * ln.dx;
+    *out = ln;
+    return 1;
+}
+
+/* Obstacle neighbours (nearest first) and their ORCA lines; returns numObstLines (<= 2 per rectangle for an agent
+ * outside it, 0 for one inside). */
+static int orca_obstacle_lines(const double* rects, int n_obst, float px, float py, float vx, float vy, float radius,
+                               float max_speed, float time_horizon_obst, orca_line* L) {
+    int nb_rect[4 * CAO_MAXOBST], nb_edge[4 * CAO_MAXOBST], nn = 0;
+    float nb_d[4 * CAO_MAXOBST];
+    const float range = time_horizon_obst * max_speed + radius, range_sq = range * range;
+    orca_vertex V[4];
+    if (n_obst > CAO_MAXOBST) n_obst = CAO_MAXOBST;
+    for (int r = 0; r < n_obst; r++) {
+        orca_rect_vertices(rects + 4 * r, V);
+        for (int k = 0; k < 4; k++) {
+            const orca_vertex *o1 = &V[k], *o2 = &V[(k + 1) & 3];
+            /* agentLeftOfLine = leftOf(o1, o2, position) = det(o1 - position, o2 - o1) */
+            const float left = detf(o1->x - px, o1->y - py, o2->x - o1->x, o2->y - o1->y);
+            const float ex = o2->x - o1->x, ey = o2->y - o1->y;
+            const float dsq_line = (left * left) / (ex * ex + ey * ey);
+            if (!(dsq_line < range_sq) || !(left < 0.0f)) continue; /* only from its right side (the agent can see it) */
+            const float dsq = dist_sq_point_segment(o1->x, o1->y, o2->x, o2->y, px, py);
+            if (!(dsq < range_sq)) continue;
+            int i = nn++; /* Agent::insertObstacleNeighbor: insertion sort, strict < */
+            while (i != 0 && dsq < nb_d[i - 1]) { nb_d[i] = nb_d[i - 1]; nb_rect[i] = nb_rect[i - 1]; nb_edge[i] = nb_edge[i - 1]; i--; }
+            nb_d[i] = dsq; nb_rect[i] = r; nb_edge[i] = k;
+        }
+    }
+    const float inv_tho = 1.0f / time_horizon_obst;
+    int nl = 0;
+    for (int q = 0; q < nn; q++) {
+        orca_rect_vertices(rects + 4 * nb_rect[q], V);
+        const int k = nb_edge[q];
+        orca_line ln;
+        if (orca_obstacle_line(&V[k], &V[(k + 1) & 3], &V[(k + 3) & 3], &V[(k + 2) & 3], px, py, vx, vy, radius, inv_tho, L, nl, &ln))
+            L[nl++] = ln;
+    }
+    return nl;
+}
+
 /* RVOPolicy.find_next_action (policies/RVOPolicy.py:53-117), ego LP only.
- * Simulator parameters RVOPolicy.py:25-28: timeStep 0.1, neighborDist inf, maxNeighbors 10,
- * timeHorizon 5.  Neighbours are visited in index order (the real library's k-d tree order
- * is unpinned), nearest first, at most 10.  collab: line.point = v + collab*u (assumed
- * semantics of the mit-acl fork's setAgentCollabCoeff; stock RVO2 uses 0.5). */
-void cao_orca_action(int M, int ego, const double* pos, const double* vel, const double* goal,
-                     const double* pref_speed, const double* radius, double heading, double collab,
-                     double dt, double* action_out) {
+ * Simulator parameters RVOPolicy.py:25-28: timeStep 0.1, neighborDist inf, maxNeighbors =
+ * Config.MAX_NUM_AGENTS_IN_ENVIRONMENT (RVOPolicy.py:15), timeHorizon = timeHorizonObst = 5.  Neighbours are visited in
+ * index order (the real library's k-d tree order is unpinned), nearest first, at most max_neighbors.  collab:
+ * line.point = v + collab*u (assumed semantics of the mit-acl fork's setAgentCollabCoeff; stock RVO2 uses 0.5).
+ * rects [n_obst][4] = xl, yl, xu, yu (may be NULL): obstacle lines come first and are hard constraints in
+ * linearProgram3.  new_vel_out (optional): the fp32 velocity the linear programs chose, lines_out / n_lines_out
+ * (optional): the half-planes in solve order and {numObstLines, total}. */
+void cao_orca_action_ex(int M, int ego, const double* pos, const double* vel, const double* goal,
+                        const double* pref_speed, const double* radius, double heading, double collab,
+                        double dt, int max_neighbors, const double* rects, int n_obst, double* action_out,
+                        float* new_vel_out, float* lines_out, int* n_lines_out) {
     float p[64][2], v[64][2], r[64];
     for (int a = 0; a < M; a++) {
         p[a][0] = (float)pos[2 * a]; p[a][1] = (float)pos[2 * a + 1];
@@ -429,22 +646,28 @@ void cao_orca_action(int M, int ego, const double* pos, const double* vel, const
     float pvx = (float)(sc * gx), pvy = (float)(sc * gy);
     float max_speed = (float)pref_speed[ego];
     float time_step = (float)dt, time_horizon = 5.0f;
-    /* neighbour list: insertion by distSq, strict <, max 10 (Agent::insertAgentNeighbor) */
-    int nb[10]; float nd[10]; int nn = 0;
+    /* neighbour list: insertion by distSq, strict <, at most maxNeighbors (Agent::insertAgentNeighbor) */
+    int nb[64]; float nd[64]; int nn = 0;
+    if (max_neighbors < 0) max_neighbors = 0;
+    if (max_neighbors > 63) max_neighbors = 63;
     float range_sq = INFINITY;
     for (int a = 0; a < M; a++) {
         if (a == ego) continue;
         float dx = p[ego][0] - p[a][0], dy = p[ego][1] - p[a][1];
         float dsq = dx * dx + dy * dy;
-        if (dsq < range_sq) {
-            if (nn < 10) nn++;
+        if (max_neighbors > 0 && dsq < range_sq) {
+            if (nn < max_neighbors) nn++;
             int i = nn - 1;
             while (i != 0 && dsq < nd[i - 1]) { nb[i] = nb[i - 1]; nd[i] = nd[i - 1]; i--; }
             nb[i] = a; nd[i] = dsq;
-            if (nn == 10) range_sq = nd[nn - 1];
+            if (nn == max_neighbors) range_sq = nd[nn - 1];
         }
     }
-    orca_line L[10];
+    orca_line Lall[CAO_MAXLINES];
+    const int num_obst = (rects && n_obst > 0)
+        ? orca_obstacle_lines(rects, n_obst, p[ego][0], p[ego][1], v[ego][0], v[ego][1], r[ego], max_speed, time_horizon, Lall)
+        : 0;
+    orca_line* L = Lall + num_obst;
     float inv_th = 1.0f / time_horizon;
     float c = (float)collab;
     for (int k = 0; k < nn; k++) {
@@ -494,8 +717,16 @@ void cao_orca_action(int M, int ego, const double* pos, const double* vel, const
         L[k] = ln;
     }
     float nvx, nvy;
-    int fail = lp2(L, nn, max_speed, pvx, pvy, 0, &nvx, &nvy);
-    if (fail < nn) lp3(L, nn, fail, max_speed, &nvx, &nvy);
+    const int nl = num_obst + nn;
+    int fail = lp2(Lall, nl, max_speed, pvx, pvy, 0, &nvx, &nvy);
+    if (fail < nl) lp3(Lall, nl, num_obst, fail, max_speed, &nvx, &nvy);
+    if (new_vel_out) { new_vel_out[0] = nvx; new_vel_out[1] = nvy; }
+    if (n_lines_out) { n_lines_out[0] = num_obst; n_lines_out[1] = nl; }
+    if (lines_out)
+        for (int k = 0; k < nl; k++) {
+            lines_out[4 * k] = Lall[k].px; lines_out[4 * k + 1] = Lall[k].py;
+            lines_out[4 * k + 2] = Lall[k].dx; lines_out[4 * k + 3] = Lall[k].dy;
+        }
     /* Agent::update: position_ += velocity_ * timeStep_ (fp32) */
     float npx = p[ego][0] + nvx * time_step, npy = p[ego][1] + nvy * time_step;
     /* back in Python, fp64 (RVOPolicy.py:91-106) */
@@ -512,6 +743,13 @@ void cao_orca_action(int M, int ego, const double* pos, const double* vel, const
     }
     action_out[0] = speed;
     action_out[1] = dh;
+}
+
+/* free space, maxNeighbors 10: the entry point the property tests of round 1 use */
+void cao_orca_action(int M, int ego, const double* pos, const double* vel, const double* goal,
+                     const double* pref_speed, const double* radius, double heading, double collab,
+                     double dt, double* action_out) {
+    cao_orca_action_ex(M, ego, pos, vel, goal, pref_speed, radius, heading, collab, dt, 10, NULL, 0, action_out, NULL, NULL, NULL);
 }
 
 /* _take_action policy dispatch (env.py:287-340) for one agent: returns the fp32-rounded action */
@@ -537,9 +775,11 @@ static void select_action(cao_env* e, int w, int i, const double* ext, float* ac
         case CAO_POL_RVO: {
             double out[2];
             int n = e->nagents[w];
-            cao_orca_action(n, i, e->f[CAO_F_POS] + 2 * base, e->f[CAO_F_VEL] + 2 * base, e->goal + 2 * base,
-                            e->pref_speed + base, e->radius + base, e->f[CAO_F_HEADING][a], e->coop[a],
-                            e->cfg.dt, out);
+            const int maxnb = e->cfg.rvo_max_neighbors > 0 ? e->cfg.rvo_max_neighbors : e->M; /* RVOPolicy.py:15 */
+            cao_orca_action_ex(n, i, e->f[CAO_F_POS] + 2 * base, e->f[CAO_F_VEL] + 2 * base, e->goal + 2 * base,
+                               e->pref_speed + base, e->radius + base, e->f[CAO_F_HEADING][a], e->coop[a],
+                               e->cfg.dt, maxnb, e->Kobs ? e->sc_obst + (size_t)w * e->Kobs * 4 : NULL,
+                               e->Kobs ? e->nobst[w] : 0, out, NULL, NULL, NULL);
             a0 = out[0]; a1 = out[1]; break;
         }
     }
@@ -708,6 +948,18 @@ void cao_step(cao_env* e, const double* ext_actions) {
         sense_world(e, w);
         done_world(e, w);
     }
+}
+
+/* bench.py's cpu_baseline: fix the size of the thread team the world loops use (the OMP_NUM_THREADS variable is read
+ * only when libgomp starts, i.e. before bench.py could set it) and report the size actually in force. */
+int cao_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+    return omp_get_max_threads();
+#else
+    (void)n;
+    return 1;
+#endif
 }
 
 /* bench.py's cpu_baseline loop in one call: n_steps x { step every world; restart the worlds whose game is over on the

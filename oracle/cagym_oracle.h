@@ -39,7 +39,10 @@ typedef struct {
     int32_t collide_with_static; /* Config.COLLISION_AV_W_STATIC_AGENT (config.py:52) */
     int32_t laserscan;         /* 1: agents carry LaserScanSensor */
     double dt;                 /* Config.DT (config.py:29) */
+    int32_t rvo_max_neighbors; /* RVO maxNeighbors; 0 = max_agents (Config.MAX_NUM_AGENTS_IN_ENVIRONMENT, RVOPolicy.py:15) */
+    int32_t reserved;
 } cao_config;
+#define CAO_MAXOBST 64 /* rectangles per world the ORCA obstacle code looks at */
 
 typedef struct cao_env cao_env;
 
@@ -57,6 +60,7 @@ void cao_reset(cao_env* e, const uint8_t* world_mask);
 /* ext_actions[N,M,2] doubles (may be NULL when no agent needs one). */
 void cao_step(cao_env* e, const double* ext_actions);
 void cao_run(cao_env* e, int n_steps); /* n_steps x (step all worlds, restart finished ones) */
+int cao_set_threads(int n);            /* OpenMP team size of the world loops (n <= 0: leave); returns the size in force */
 
 /* zero-copy views for the tests; field ids below */
 enum { CAO_F_POS = 0, CAO_F_VEL, CAO_F_HEADING, CAO_F_SPEED, CAO_F_DELTA_HEADING, CAO_F_DIST_TO_GOAL,
@@ -77,6 +81,14 @@ void cao_rasterize(const double* obstacles, int n_obst, uint8_t* map300);
 void cao_orca_action(int M, int ego, const double* pos, const double* vel, const double* goal,
                      const double* pref_speed, const double* radius, double heading, double collab,
                      double dt, double* action_out);
+/* the same with RVO maxNeighbors and the world's rectangles rects[n_obst][4] = xl, yl, xu, yu (RVOPolicy.py:56-57;
+ * obstacle half of Agent::computeNewVelocity, numObstLines protected in linearProgram3).  Optional outputs:
+ * new_vel_out[2] fp32 velocity chosen by the linear programs, lines_out[n][4] half-planes (point, direction) in solve
+ * order, n_lines_out[2] = {numObstLines, total lines}. */
+void cao_orca_action_ex(int M, int ego, const double* pos, const double* vel, const double* goal,
+                        const double* pref_speed, const double* radius, double heading, double collab,
+                        double dt, int max_neighbors, const double* rects, int n_obst, double* action_out,
+                        float* new_vel_out, float* lines_out, int* n_lines_out);
 
 /* GA3C-CADRL state vectors out[N,M,76] (policies/GA3CCADRLPolicy.py:45-106) */
 void cao_ga3c_states(cao_env* e, int max_observed, double* out);

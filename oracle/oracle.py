@@ -25,7 +25,7 @@ GO_AGENT0, GO_ALL, GO_LEARNING = 0, 1, 2
 class Config(C.Structure):
     _fields_ = [("n_worlds", C.c_int32), ("max_agents", C.c_int32), ("max_obstacles", C.c_int32),
                 ("game_over_mode", C.c_int32), ("collide_with_static", C.c_int32), ("laserscan", C.c_int32),
-                ("dt", C.c_double)]
+                ("dt", C.c_double), ("rvo_max_neighbors", C.c_int32), ("reserved", C.c_int32)]
 
 
 def build(force=False):
@@ -41,8 +41,7 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB):
-            build()
+        build()  # no-op unless a source is newer than the library
         L = C.CDLL(LIB)
         L.cao_create.restype = C.c_void_p
         L.cao_create.argtypes = [C.POINTER(Config)]
@@ -51,11 +50,15 @@ def lib():
         L.cao_reset.argtypes = [C.c_void_p, C.c_void_p]
         L.cao_step.argtypes = [C.c_void_p, C.c_void_p]
         L.cao_run.argtypes = [C.c_void_p, C.c_int]
+        L.cao_set_threads.restype = C.c_int
+        L.cao_set_threads.argtypes = [C.c_int]
         for n, t in (("cao_f64", C.c_double), ("cao_u8", C.c_uint8), ("cao_i32", C.c_int32)):
             getattr(L, n).restype = C.POINTER(t)
             getattr(L, n).argtypes = [C.c_void_p, C.c_int]
         L.cao_rasterize.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.cao_orca_action.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_double] * 3 + [C.c_void_p]
+        L.cao_orca_action_ex.argtypes = ([C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_double] * 3 + [C.c_int, C.c_void_p, C.c_int]
+                                         + [C.c_void_p] * 4)
         L.cao_ga3c_states.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.cao_edt.argtypes = [C.c_void_p] * 3
         L.cao_ig_check_visibility.argtypes = [C.c_void_p] * 3
@@ -86,9 +89,10 @@ class OracleEnv(object):
     """N worlds x M agent slots, fp64, scalar CPU."""
 
     def __init__(self, N, M, max_obstacles=0, game_over_mode=GO_AGENT0, collide_with_static=False,
-                 laserscan=False, dt=0.1):
+                 laserscan=False, dt=0.1, rvo_max_neighbors=0):
         self.N, self.M, self.K, self.Kobs = N, M, M - 1, max_obstacles
-        self.cfg = Config(N, M, max_obstacles, game_over_mode, int(collide_with_static), int(laserscan), dt)
+        self.cfg = Config(N, M, max_obstacles, game_over_mode, int(collide_with_static), int(laserscan), dt,
+                          int(rvo_max_neighbors), 0)
         self.L = lib()
         self.h = self.L.cao_create(C.byref(self.cfg))
 
@@ -169,6 +173,25 @@ def orca_action(pos, vel, goal, pref_speed, radius, ego, heading, collab=0.5, dt
     lib().cao_orca_action(pos.shape[0], ego, _p(pos), _p(vel), _p(goal), _p(ps), _p(rd), float(heading),
                           float(collab), float(dt), _p(out))
     return out
+
+
+def orca_action_ex(pos, vel, goal, pref_speed, radius, ego, heading, collab=0.5, dt=0.1, max_neighbors=10, rects=None):
+    """RVO ego solve with static rectangles [n, 4] = xl, yl, xu, yu.  Returns dict(action[2], new_vel[2] fp32,
+    lines [n_lines, 4] (point, direction), n_obst_lines)."""
+    pos = np.ascontiguousarray(pos, dtype=np.float64)
+    vel = np.ascontiguousarray(vel, dtype=np.float64)
+    goal = np.ascontiguousarray(goal, dtype=np.float64)
+    ps = np.ascontiguousarray(pref_speed, dtype=np.float64)
+    rd = np.ascontiguousarray(radius, dtype=np.float64)
+    rc = None if rects is None else np.ascontiguousarray(np.asarray(rects, dtype=np.float64).reshape(-1, 4))
+    out = np.zeros(2)
+    nv = np.zeros(2, dtype=np.float32)
+    lines = np.zeros((192, 4), dtype=np.float32)
+    nl = np.zeros(2, dtype=np.int32)
+    lib().cao_orca_action_ex(pos.shape[0], ego, _p(pos), _p(vel), _p(goal), _p(ps), _p(rd), float(heading), float(collab),
+                             float(dt), int(max_neighbors), _p(rc), 0 if rc is None else rc.shape[0], _p(out), _p(nv),
+                             _p(lines), _p(nl))
+    return {"action": out, "new_vel": nv, "lines": lines[:nl[1]].copy(), "n_obst_lines": int(nl[0])}
 
 
 # ---- information-gain primitives (one world) --------------------------------------------------------

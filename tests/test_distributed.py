@@ -34,8 +34,9 @@ def _worker(rank, ws, port, total, q):
     local = {"stat_return": -ids, "stat_episodes": torch.ones(count, dtype=torch.int32),
              "stat_steps": (ids * 2).to(torch.int32),
              "stat_outcomes": torch.stack([ids, ids * 0, ids * 0 + 1], 1).to(torch.int32)}
+    local["stat_steps"] = local["stat_steps"] + (1 << 25)  # beyond fp32's exact integers: the records carry int32
     packed = st.pack_episode_stats(local)
-    g = st.all_gather_episode_stats(packed)
+    g = st.all_gather_episode_stats(packed, total_worlds=total)
     if rank == 0:
         q.put(g.numpy())
     dist.barrier()
@@ -50,11 +51,10 @@ def test_shard_worlds_partition():
             assert s0 + c0 == s1
 
 
-def test_allgather_episode_stats_gloo_world2():
+def _gather_world2(total):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    total = 64
     procs = [ctx.Process(target=_worker, args=(r, 2, port, total, q)) for r in range(2)]
     for p in procs:
         p.start()
@@ -62,13 +62,25 @@ def test_allgather_episode_stats_gloo_world2():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert g.shape == (total, 6)
-    ids = np.arange(total, dtype=np.float32)
-    assert np.array_equal(g[:, 0], -ids) and np.array_equal(g[:, 2], 2 * ids) and np.array_equal(g[:, 3], ids)
+    assert g.shape == (total, 6) and g.dtype == np.int32
+    ids = np.arange(total)
+    u = stats.unpack_episode_stats(torch.from_numpy(g))
+    assert np.array_equal(u["return_sum"].numpy(), -ids.astype(np.float64))
+    assert np.array_equal(u["steps"].numpy(), 2 * ids + (1 << 25)) and np.array_equal(u["n_goal"].numpy(), ids)
     s = stats.summarize(torch.from_numpy(g))
     assert s["episodes"] == total
+    assert s["mean_steps"] == float((2 * ids + (1 << 25)).sum()) / total
+
+
+def test_allgather_episode_stats_gloo_world2():
+    _gather_world2(64)
+
+
+def test_allgather_episode_stats_gloo_world2_ragged():
+    """total % world_size != 0: shard_worlds gives rank 0 one world more; the gather pads and trims."""
+    _gather_world2(63)
 
 
 def test_single_process_passthrough():
-    x = torch.zeros(4, 6)
+    x = torch.zeros(4, 6, dtype=torch.int32)
     assert stats.all_gather_episode_stats(x) is x
