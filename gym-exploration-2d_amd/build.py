@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libcagym_hip.so")
 SOURCES = ["cagym_api.hip"]
-HEADERS = ["cagym_device.h", "cagym_orca.h", "cagym_kernels.h", "cagym_kernels2.h", "cagym_ig.h", "cagym_ga3c.h", "cagym_gen.h", "cagym_dmcts.h", "../../include/cagym.h"]
+HEADERS = ["cagym_device.h", "cagym_orca.h", "cagym_kernels.h", "cagym_kernels2.h", "cagym_kernels3.h", "cagym_ig.h", "cagym_ga3c.h", "cagym_gen.h", "cagym_dmcts.h", "../../include/cagym.h"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wno-unused-value",

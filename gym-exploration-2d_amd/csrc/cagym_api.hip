@@ -10,6 +10,7 @@
 #include "../../include/cagym.h"
 #include "cagym_kernels.h"
 #include "cagym_kernels2.h"
+#include "cagym_kernels3.h"
 #include "cagym_ig.h"
 #include "cagym_ga3c.h"
 #include "cagym_gen.h"
@@ -31,7 +32,7 @@ struct Env {
     uint32_t* ig_any = nullptr;
     bool ig_ready = false;
     int any_rvo = 1;
-    int generation = 2;  // CAGYM_KERNEL=v1 selects the one-lane-per-agent kernels (A/B only)
+    int generation = 3;  // CAGYM_KERNEL=v1 / v2 select the older kernel generations (bitwise A/B only)
     int wpw10 = 5;       // worlds per workgroup of the M = 10 kernels (4 while all workgroups are co-resident)
 };
 
@@ -131,6 +132,11 @@ inline size_t lds2_bytes(const Env* e) {
     return cagym_lds2_bytes(M, cagym_as(M, wpw_spec(e)));
 }
 
+inline size_t lds3_bytes(const Env* e) {
+    const int M = e->cfg.max_agents;
+    return cagym_lds3_bytes(M, cagym_as(M, wpw_spec(e)), spec2(e).nt);
+}
+
 inline int n_waves(const Env* e) {
     int wpw = CAGYM_WAVE / e->cfg.max_agents;
     return (e->cfg.n_worlds + wpw - 1) / wpw;
@@ -142,6 +148,13 @@ void set_lds_attr2(int lds2) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<NT, MT, WP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<NT, MT, WP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<NT, MT, WP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+}
+template <int NT, int MT, int WP>
+void set_lds_attr3(int lds3) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_step3<NT, MT, WP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds3);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_step3<NT, MT, WP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds3);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout3<NT, MT, WP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds3);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout3<NT, MT, WP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds3);
 }
 
 // the one place that maps a handle to its generation-2 kernel instantiation
@@ -227,6 +240,7 @@ int cagym_create(const cagym_config* cfg, void** env_out) {
     {
         const char* g = getenv("CAGYM_KERNEL");
         if (g && (!strcmp(g, "v1") || !strcmp(g, "1"))) e->generation = 1;
+        if (g && (!strcmp(g, "v2") || !strcmp(g, "2"))) e->generation = 2;
         {
             hipDeviceProp_t prop;
             int cus = 256;
@@ -236,9 +250,10 @@ int cagym_create(const cagym_config* cfg, void** env_out) {
             const char* w = getenv("CAGYM_WPW10");  // diagnostics
             if (w && (w[0] == '4' || w[0] == '5')) e->wpw10 = w[0] - '0';
         }
-        int lds2 = (int)lds2_bytes(e);
-        if (lds2 > 160 * 1024) e->generation = 1;
-#define SETATTR(NT, MT, WP) set_lds_attr2<NT, MT, WP>(lds2)
+        int lds2 = (int)lds2_bytes(e), lds3 = (int)lds3_bytes(e);
+        if (e->generation == 3 && lds3 > 160 * 1024) e->generation = 2;
+        if (e->generation == 2 && lds2 > 160 * 1024) e->generation = 1;
+#define SETATTR(NT, MT, WP) set_lds_attr2<NT, MT, WP>(lds2); set_lds_attr3<NT, MT, WP>(lds3)
         CAGYM_DISPATCH2(e, SETATTR);
 #undef SETATTR
     }
@@ -391,7 +406,12 @@ int cagym_step(void* env, const float* ext_actions, const cagym_outputs* out, vo
     DEVGUARD(e);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     CagymOut o = to_out(out);
-    if (e->generation == 2) {
+    if (e->generation == 3) {
+        const size_t lds3 = lds3_bytes(e);
+#define STEP3(NT, MT, WP) hipLaunchKernelGGL((k_step3<NT, MT, WP, false>), dim3(n_wg2(e)), dim3(NT), lds3, st, e->D, ext_actions, o, e->any_rvo)
+        CAGYM_DISPATCH2(e, STEP3);
+#undef STEP3
+    } else if (e->generation == 2) {
         const size_t lds2 = lds2_bytes(e);
 #define STEP2(NT, MT, WP) hipLaunchKernelGGL((k_step2<NT, MT, WP, false>), dim3(n_wg2(e)), dim3(NT), lds2, st, e->D, ext_actions, o, e->any_rvo)
         CAGYM_DISPATCH2(e, STEP2);
@@ -410,13 +430,18 @@ int cagym_step_autoreset(void* env, const float* ext_actions, const cagym_output
     DEVGUARD(e);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     CagymOut o = to_out(out);
-    if (e->generation == 2) {
+    if (e->generation == 3) {
+        const size_t lds3 = lds3_bytes(e);
+#define STEP3(NT, MT, WP) hipLaunchKernelGGL((k_step3<NT, MT, WP, true>), dim3(n_wg2(e)), dim3(NT), lds3, st, e->D, ext_actions, o, e->any_rvo)
+        CAGYM_DISPATCH2(e, STEP3);
+#undef STEP3
+    } else if (e->generation == 2) {
         const size_t lds2 = lds2_bytes(e);
 #define STEP2(NT, MT, WP) hipLaunchKernelGGL((k_step2<NT, MT, WP, true>), dim3(n_wg2(e)), dim3(NT), lds2, st, e->D, ext_actions, o, e->any_rvo)
         CAGYM_DISPATCH2(e, STEP2);
 #undef STEP2
     } else
-        return fail(e, CAGYM_E_UNSUPPORTED, "cagym_step_autoreset needs the generation-2 kernels");
+        return fail(e, CAGYM_E_UNSUPPORTED, "cagym_step_autoreset needs the generation-2 or -3 kernels");
     HIPCHK(e, hipGetLastError());
     if (e->cfg.laserscan && o.laserscan) return cagym_laserscan(env, o.laserscan, stream);
     return CAGYM_OK;
@@ -433,7 +458,17 @@ int cagym_rollout(void* env, int n_steps, int auto_reset, const cagym_outputs* o
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     CagymOut o = to_out(out);
     size_t lds = cagym_lds_bytes(e->cfg.max_agents);
-    if (e->generation == 2) {
+    if (e->generation == 3) {
+        const size_t lds3 = lds3_bytes(e);
+        const dim3 g(n_wg2(e));
+#define ROLL3(NT, MT, WP)                                                                                              \
+    do {                                                                                                           \
+        if (auto_reset) hipLaunchKernelGGL((k_rollout3<NT, MT, WP, true>), g, dim3(NT), lds3, st, e->D, n_steps, o, e->any_rvo); \
+        else hipLaunchKernelGGL((k_rollout3<NT, MT, WP, false>), g, dim3(NT), lds3, st, e->D, n_steps, o, e->any_rvo);         \
+    } while (0)
+        CAGYM_DISPATCH2(e, ROLL3);
+#undef ROLL3
+    } else if (e->generation == 2) {
         const size_t lds2 = lds2_bytes(e);
         const dim3 g(n_wg2(e));
 #define ROLL2(NT, MT, WP)                                                                                              \
@@ -454,10 +489,10 @@ int cagym_rollout(void* env, int n_steps, int auto_reset, const cagym_outputs* o
 int cagym_kernel_name(void* env, int rollout, int auto_reset, char* buf, int buf_len) {
     Env* e = reinterpret_cast<Env*>(env);
     if (!e || !buf || buf_len < 1) return fail(e, CAGYM_E_INVALID, "bad arguments");
-    if (e->generation == 2) {
+    if (e->generation >= 2) {
         const Spec2 sp = spec2(e);
-        snprintf(buf, (size_t)buf_len, "%s<%d, %d, %d, %s>", rollout ? "k_rollout2" : "k_step2", sp.nt, sp.mt, sp.wpw,
-                 auto_reset ? "true" : "false");
+        snprintf(buf, (size_t)buf_len, "%s%d<%d, %d, %d, %s>", rollout ? "k_rollout" : "k_step", e->generation, sp.nt, sp.mt,
+                 sp.wpw, auto_reset ? "true" : "false");
     } else if (rollout) {
         snprintf(buf, (size_t)buf_len, "k_rollout<%s>", auto_reset ? "true" : "false");
     } else {

@@ -1,0 +1,717 @@
+// cagym_kernels3.h -- software-pipelined env.step() kernels (generation 3, the default).
+//
+// Why (profiles/r2/wgtrace_*.txt, stamps_gen2_*.txt): a 4096 x 10 batch is 16 worlds per CU.  A generation-2 workgroup
+// alone on its CU still needs 8.3 us per step and four co-resident ones 10.1 us: the launch is bound by the LENGTH OF
+// THE DEPENDENT CHAIN of one step (six phases separated by barriers, the per-agent phases on one wave with the other
+// three idle), not by throughput.  Only S1(t) -> half-planes(t+1) -> linear programs(t+1) -> S1(t+1) is a true cycle;
+// everything else of a step is moved off it:
+//
+//   phase C   linear programs of step t on the first waves (8-lane groups)    ||  OAS rows of step t-1 on the idle waves,
+//   phase D   S1(t) on wave 0: action maps + dynamics, result kept in VGPRs   ||  64-row chunks claimed from an LDS counter
+//             barrier; wave 0 publishes the moved agents to LDS; barrier
+//   phase A   pair distances / collisions / OAS keys of step t + the fp32 squared distances the next ORCA ranking needs
+//             (one lane per unordered pair); last wave: ego frames + preferred velocities
+//   phase B   S2(t) on wave 0: rewards, done, game_over, auto-reset            ||  half-planes of step t+1 on waves 1.., each
+//             pair lane also ranks its two half-planes into nearest-first order (the LP groups start from sorted lines)
+//   (rare)    a world was reset in S2: keys, distances, preferred velocities and half-planes are rebuilt in two extra phases
+//
+// Wave 0 waits for the other LP waves on an LDS counter (release/acquire at workgroup scope), not on a barrier, so the
+// row workers never stop between C and D.  Arithmetic is shared with generations 1 and 2 (cagym_device.h, cagym_orca.h):
+// all three produce bit-identical results (tests/test_hip_parity.py).
+#pragma once
+#include "cagym_kernels2.h"
+
+struct Lds3 {
+    double *tpx, *tpy, *tvx, *tvy, *tr, *tprx, *tpry;
+    double *th, *the, *tdg, *ttrem, *tt, *tgx, *tgy, *tpref, *tspeed, *tdh, *taux0, *taux1, *tcoopd;
+    float2* tact;
+    float* tcoop;
+    uint32_t* tst;
+    int* tstep;
+    int* tmoved;   // [AS] the agent moved in this step's S1 (ego frame still to be updated)
+    int* trvo;     // [AS] live RVO ego as of the last S1 (the next step's half-planes are built beside S2)
+    int* wn;       // [32] agents per world of this workgroup
+    int* flag;     // [8]  0: a world was reset this step   1: OAS row chunks claimed   2: LP waves finished
+    float2* lpv;   // [AS] preferred (optimisation) velocity of each ego
+    float2* lpc;   // [AS] pref velocity clipped to maxSpeed = LP start; LP result afterwards
+    float* lpr;    // [AS] maxSpeed of the ego (LP radius)
+    int* lpk;      // [AS] compact list of the busy egos
+    int* busy;     // [AS] some half-plane of the ego is violated by its LP start
+    float* dsq;      // [AS*MP]       squared centre distance ego->slot, fp32 as RVO2 (+inf = no such neighbour)
+    float4* sorted;  // [MAXNB][AS]   half-planes nearest-first
+    float4* lp3;     // [NT]          linearProgram3 scratch, GW entries per LP group
+    double* keys;    // [AS*MP]       OAS sort key (-inf = not observed)
+    double* gap;     // [AS*MP]       d - (r_i + r_j) for the lower index of a pair, else +inf
+    uint8_t* hit;    // [AS*MP]       pair collides
+};
+
+__host__ __device__ inline size_t cagym_lds3_head(int AS) {
+    return (size_t)20 * AS * 8 + AS * 8 + (size_t)5 * AS * 4 + 32 * 4 + 8 * 4 + (size_t)2 * AS * 8 + (size_t)3 * AS * 4;
+}
+__host__ __device__ inline size_t cagym_lds3_bytes(int M, int AS, int NT) {
+    const size_t MP = cagym_mp(M);
+    return a16(cagym_lds3_head(AS)) + a16(AS * MP * 4) + (size_t)CAGYM_MAXNB * AS * 16 + (size_t)NT * 16 + 2 * AS * MP * 8 + a16(AS * MP);
+}
+
+__device__ __forceinline__ Lds3 carve_lds3(unsigned char* smem, int M, int AS, int NT) {
+    Lds3 W;
+    const size_t MP = cagym_mp(M);
+    W.tpx = reinterpret_cast<double*>(smem);
+    W.tpy = W.tpx + AS; W.tvx = W.tpy + AS; W.tvy = W.tvx + AS; W.tr = W.tvy + AS; W.tprx = W.tr + AS; W.tpry = W.tprx + AS;
+    W.th = W.tpry + AS; W.the = W.th + AS; W.tdg = W.the + AS; W.ttrem = W.tdg + AS; W.tt = W.ttrem + AS;
+    W.tgx = W.tt + AS; W.tgy = W.tgx + AS; W.tpref = W.tgy + AS; W.tspeed = W.tpref + AS; W.tdh = W.tspeed + AS;
+    W.taux0 = W.tdh + AS; W.taux1 = W.taux0 + AS; W.tcoopd = W.taux1 + AS;
+    W.tact = reinterpret_cast<float2*>(W.tcoopd + AS);
+    W.lpv = W.tact + AS;
+    W.lpc = W.lpv + AS;
+    W.tcoop = reinterpret_cast<float*>(W.lpc + AS);
+    W.tst = reinterpret_cast<uint32_t*>(W.tcoop + AS);
+    W.tstep = reinterpret_cast<int*>(W.tst + AS);
+    W.tmoved = W.tstep + AS;
+    W.trvo = W.tmoved + AS;
+    W.lpr = reinterpret_cast<float*>(W.trvo + AS);
+    W.lpk = reinterpret_cast<int*>(W.lpr + AS);
+    W.busy = W.lpk + AS;
+    W.wn = W.busy + AS;
+    W.flag = W.wn + 32;
+    unsigned char* u = smem + a16(cagym_lds3_head(AS));
+    W.dsq = reinterpret_cast<float*>(u);
+    u += a16(AS * MP * 4);
+    W.sorted = reinterpret_cast<float4*>(u);
+    u += (size_t)CAGYM_MAXNB * AS * 16;
+    W.lp3 = reinterpret_cast<float4*>(u);
+    u += (size_t)NT * 16;
+    W.keys = reinterpret_cast<double*>(u);
+    W.gap = W.keys + AS * MP;
+    W.hit = reinterpret_cast<uint8_t*>(W.gap + AS * MP);
+    return W;
+}
+
+__device__ __forceinline__ void lds3_store_moved(const Lds3& W, const Agent& A, int lane) {
+    W.tpx[lane] = A.px; W.tpy[lane] = A.py; W.tvx[lane] = A.vx; W.tvy[lane] = A.vy;
+    W.tprx[lane] = A.prx; W.tpry[lane] = A.pry;
+    W.th[lane] = A.h; W.the[lane] = A.he; W.tdg[lane] = A.dg; W.ttrem[lane] = A.trem; W.tt[lane] = A.t;
+    W.tspeed[lane] = A.speed; W.tdh[lane] = A.dh; W.taux0[lane] = A.aux0; W.taux1[lane] = A.aux1;
+    W.tact[lane] = make_float2(A.a0, A.a1);
+    W.tst[lane] = A.st;
+    W.tstep[lane] = A.step;
+}
+__device__ __forceinline__ void lds3_store_agent(const Lds3& W, const Agent& A, int lane) {
+    lds3_store_moved(W, A, lane);
+    W.tr[lane] = A.r; W.tgx[lane] = A.gx; W.tgy[lane] = A.gy; W.tpref[lane] = A.pref;
+    W.tcoopd[lane] = A.coop;
+    W.tcoop[lane] = (float)A.coop;
+}
+__device__ __forceinline__ Agent lds3_load_agent(const Lds3& W, int lane) {
+    Agent A;
+    A.px = W.tpx[lane]; A.py = W.tpy[lane]; A.vx = W.tvx[lane]; A.vy = W.tvy[lane]; A.r = W.tr[lane];
+    A.prx = W.tprx[lane]; A.pry = W.tpry[lane];
+    A.h = W.th[lane]; A.he = W.the[lane]; A.dg = W.tdg[lane]; A.trem = W.ttrem[lane]; A.t = W.tt[lane];
+    A.gx = W.tgx[lane]; A.gy = W.tgy[lane]; A.pref = W.tpref[lane]; A.speed = W.tspeed[lane]; A.dh = W.tdh[lane];
+    A.aux0 = W.taux0[lane]; A.aux1 = W.taux1[lane]; A.coop = W.tcoopd[lane];
+    const float2 a = W.tact[lane];
+    A.a0 = a.x; A.a1 = a.y;
+    A.st = W.tst[lane];
+    A.step = W.tstep[lane];
+    return A;
+}
+
+// live RVO ego: solves an ORCA program in the next step.  S2 turns every at-goal / timed-out / collided agent into a
+// done one, so testing the three flags after S1 already tells (only a collision found by the concurrent S2 is missed:
+// that ego gets one wasted linear program, its result is never read).
+__device__ __forceinline__ int live_rvo(uint32_t st, bool active) {
+    return (active && ST_POLICY(st) == CAGYM_POL_RVO &&
+            !(st & (CAGYM_FLAG_DONE | CAGYM_FLAG_AT_GOAL | CAGYM_FLAG_RAN_OUT_OF_TIME | CAGYM_FLAG_IN_COLLISION))) ? 1 : 0;
+}
+
+// prefVelocity / maxSpeed / LP start of agent a (publish_pref_velocity of generation 2 on the Lds3 carve)
+__device__ __forceinline__ void publish_pref_velocity3(const Lds3& W, int a) {
+    const double gx = W.tgx[a] - W.tpx[a], gy = W.tgy[a] - W.tpy[a];
+    const double pref = W.tpref[a];
+    const double sc = pref / norm2(gx, gy);
+    const float ox = (float)(sc * gx), oy = (float)(sc * gy), radius = (float)pref;
+    W.lpv[a] = make_float2(ox, oy);
+    W.lpr[a] = radius;
+    float cx = ox, cy = oy;
+    if (ox * ox + oy * oy > radius * radius) {
+        const float inv = 1.0f / sqrtf(ox * ox + oy * oy);
+        cx = ox * inv * radius;
+        cy = oy * inv * radius;
+    }
+    W.lpc[a] = make_float2(cx, cy);
+    W.busy[a] = 0;
+}
+
+// unordered pair p of the workgroup -> (world of the workgroup, i, j); compile-time M or run-time M (magic division)
+template <int MT>
+__device__ __forceinline__ UPair upair_of(int p, int M) {
+    if (MT > 0) return UnorderedPairs<MT>::of(p);
+    UPair q;
+    const uint32_t npw = (uint32_t)(M * (M - 1) / 2);
+    const uint32_t inv_n = (uint32_t)(0x100000000ull / npw) + 1u, inv_m = (uint32_t)(0x100000000ull / (uint32_t)M) + 1u;
+    q.wl = npw == 1u ? p : (int)__umulhi((uint32_t)p, inv_n);  // the magic number of divisor 1 does not fit 32 bits
+    const int u = p - q.wl * (int)npw;
+    const int H = (M - 1) / 2;
+    if (u < M * H) {
+        const int k = (int)__umulhi((uint32_t)u, inv_m);
+        q.i = u - k * M;
+        q.j = q.i + k + 1;
+        if (q.j >= M) q.j -= M;
+    } else {
+        q.i = u - M * H;
+        q.j = q.i + M / 2;
+    }
+    return q;
+}
+
+// ---- phase A body: pair distances of the moved state (env.py:630-655), OAS sort keys, fp32 squared distances ------------
+template <int MT>
+__device__ __forceinline__ void pair_distances3(const CagymDev& D, const Lds3& W, int p, int M, int MP) {
+    const UPair q = upair_of<MT>(p, M);
+    const int n = W.wn[q.wl];
+    const int lo = q.wl * M + (q.i < q.j ? q.i : q.j), hi = q.wl * M + (q.i < q.j ? q.j : q.i);
+    const int slo = lo - q.wl * M, shi = hi - q.wl * M;
+    double klo = -INFINITY, khi = -INFINITY, gp = INFINITY;
+    float dq = INFINITY;
+    uint8_t ht = 0;
+    if (shi < n) {  // slo < shi < n
+        const double plx = W.tpx[lo], ply = W.tpy[lo], phx = W.tpx[hi], phy = W.tpy[hi];
+        const double dx = phx - plx, dy = phy - ply;
+        const double d = norm2(dx, dy);
+        const double rl = W.tr[lo], rh = W.tr[hi];
+        const bool skip = ST_POLICY(W.tst[hi]) == CAGYM_POL_STATIC && !D.collide_static;  // env.py:643 (Q8)
+        const double cr = rl + rh;
+        ht = (!skip && d <= cr) ? 1 : 0;
+        if (!skip) gp = d - cr;  // lower index only (Q7)
+        klo = d - rl - rh;
+        khi = d - rh - rl;
+        // Agent::computeNewVelocity's distSq of the pair, fp32: (float)p_other - (float)p_ego, squared (sign-symmetric)
+        const float rpx = (float)phx - (float)plx, rpy = (float)phy - (float)ply;
+        dq = rpx * rpx + rpy * rpy;
+    }
+    W.hit[lo * MP + shi] = ht;
+    W.hit[hi * MP + slo] = ht;
+    W.gap[lo * MP + shi] = gp;
+    W.gap[hi * MP + slo] = INFINITY;
+    W.keys[lo * MP + shi] = klo;
+    W.keys[hi * MP + slo] = khi;
+    W.dsq[lo * MP + shi] = dq;
+    W.dsq[hi * MP + slo] = dq;
+}
+
+// rank of slot sl in ego a's row of squared distances: nearest first, ties by lower index (Agent::insertAgentNeighbor)
+template <int MT>
+__device__ __forceinline__ int neighbour_rank3(const Lds3& W, int a, int sl, float dq, int MP) {
+    const float4* row = reinterpret_cast<const float4*>(W.dsq + a * MP);
+    int rank = 0;
+    constexpr int MPT = MT > 0 ? ((MT + 3) & ~3) : 0;
+    if (MT > 0) {
+#pragma unroll
+        for (int l4 = 0; l4 < MPT; l4 += 4) {
+            const float4 v = row[l4 >> 2];
+            rank += (v.x < dq) || (v.x == dq && l4 + 0 < sl);
+            rank += (v.y < dq) || (v.y == dq && l4 + 1 < sl);
+            rank += (v.z < dq) || (v.z == dq && l4 + 2 < sl);
+            rank += (v.w < dq) || (v.w == dq && l4 + 3 < sl);
+        }
+    } else {
+        for (int l4 = 0; l4 < MP; l4 += 4) {
+            const float4 v = row[l4 >> 2];
+            rank += (v.x < dq) || (v.x == dq && l4 + 0 < sl);
+            rank += (v.y < dq) || (v.y == dq && l4 + 1 < sl);
+            rank += (v.z < dq) || (v.z == dq && l4 + 2 < sl);
+            rank += (v.w < dq) || (v.w == dq && l4 + 3 < sl);
+        }
+    }
+    return rank;
+}
+
+// ---- phase B body: ORCA half-planes of one unordered pair, ranked into both egos' nearest-first line lists -----------------
+template <int MT>
+__device__ __forceinline__ void half_planes3(const CagymDev& D, const Lds3& W, int p, int M, int MP, int AS) {
+    const UPair q = upair_of<MT>(p, M);
+    const int n = W.wn[q.wl];
+    const int a = q.wl * M + q.i, b = q.wl * M + q.j;
+    const bool both = q.i < n && q.j < n;
+    const bool on_a = both && W.trvo[a] != 0;
+    const bool on_b = both && W.trvo[b] != 0;
+    if (!(on_a || on_b)) return;
+    const float vax = (float)W.tvx[a], vay = (float)W.tvy[a];
+    const OrcaPair g = orca_pair((float)W.tpx[a], (float)W.tpy[a], vax, vay, (float)((1 + 15e-2) * W.tr[a]), (float)D.dt,
+                                 W.tpx[b], W.tpy[b], W.tvx[b], W.tvy[b], W.tr[b]);
+    if (on_a) {
+        const float c = W.tcoop[a];
+        const float4 ln = make_float4(vax + c * g.ux, vay + c * g.uy, g.zx, g.zy);
+        const float2 s0 = W.lpc[a];
+        if (detf(ln.z, ln.w, ln.x - s0.x, ln.y - s0.y) > 0.0f) W.busy[a] = 1;
+        const int rank = neighbour_rank3<MT>(W, a, q.j, g.d2, MP);
+        if (rank < CAGYM_MAXNB) W.sorted[rank * AS + a] = ln;
+    }
+    if (on_b) {
+        const float c = W.tcoop[b];
+        const float4 ln = make_float4((float)W.tvx[b] - c * g.ux, (float)W.tvy[b] - c * g.uy, -g.zx, -g.zy);
+        const float2 s0 = W.lpc[b];
+        if (detf(ln.z, ln.w, ln.x - s0.x, ln.y - s0.y) > 0.0f) W.busy[b] = 1;
+        const int rank = neighbour_rank3<MT>(W, b, q.i, g.d2, MP);
+        if (rank < CAGYM_MAXNB) W.sorted[rank * AS + b] = ln;
+    }
+}
+
+// ---- one 64-row chunk of the OtherAgentsStates table (sensors/OtherAgentsStatesSensor.py:11-77), straight to HBM ----------
+__device__ __forceinline__ void oas_row3(const Lds3& W, float* oas_out, int p, int npairs, int M, int MP, int K, int wpw,
+                                         int worlds_valid, uint32_t inv_m) {
+    if (p >= npairs) return;
+    const PairIdx q = pair_of(p, M, inv_m);
+    if (q.j == q.sl || q.wl >= worlds_valid) return;
+    const int n = W.wn[q.wl];
+    float* my = oas_out + ((size_t)blockIdx.x * wpw * M + q.a) * K * 10;
+    const double kj = W.keys[q.a * MP + q.j];
+    float v[10];
+    int row;
+    if (!(kj > -INFINITY)) {  // unused row: zero (rows n-1 .. K-1 of an active agent, every row of an empty slot)
+        row = q.sl < n ? q.j - 1 : (q.j < q.sl ? q.j : q.j - 1);
+#pragma unroll
+        for (int c = 0; c < 10; c++) v[c] = 0.f;
+    } else {
+        int before = 0;  // descending key, ties by descending index (stable sort, reversed: :28-34)
+        const double2* krow = reinterpret_cast<const double2*>(W.keys + q.a * MP);
+        for (int l2 = 0; l2 < MP; l2 += 2) {
+            const double2 kk = krow[l2 >> 1];
+            before += (kk.x > kj) || (kk.x == kj && l2 + 0 > q.j);
+            before += (kk.y > kj) || (kk.y == kj && l2 + 1 > q.j);
+        }
+        row = before;
+        const int b = q.a - q.sl + q.j;
+        const double dx = W.tpx[b] - W.tpx[q.a], dy = W.tpy[b] - W.tpy[q.a];
+        const double prx = W.tprx[q.a], pry = W.tpry[q.a], orx = -pry, ory = prx;
+        const double ovx = W.tvx[b], ovy = W.tvy[b], orad = W.tr[b];
+        v[0] = (float)dx;
+        v[1] = (float)dy;
+        v[2] = (float)dot2(dx, dy, prx, pry);
+        v[3] = (float)dot2(dx, dy, orx, ory);
+        v[4] = (float)dot2(ovx, ovy, prx, pry);
+        v[5] = (float)dot2(ovx, ovy, orx, ory);
+        v[6] = (float)orad;
+        v[7] = (float)(W.tr[q.a] + orad);
+        v[8] = (float)kj;
+        v[9] = ST_POLICY(W.tst[b]) == CAGYM_POL_STATIC ? 1.f : 2.f;
+    }
+    float2* r2 = reinterpret_cast<float2*>(my + row * 10);  // rows are 40 B: 8-byte aligned
+#pragma unroll
+    for (int c = 0; c < 5; c++) r2[c] = make_float2(v[2 * c], v[2 * c + 1]);
+}
+
+// scalar observation keys of agent slot a of the workgroup (agent.py:244-248, config.py:104-215) + n_observed
+__device__ __forceinline__ void ego_obs3(const CagymDev& D, const Lds3& W, float* ego_out, int a, int M, int wpw, uint32_t inv_m) {
+    if (a >= wpw * M) return;
+    const int wl = (int)__umulhi((uint32_t)a, inv_m);
+    const int slot = a - wl * M;
+    const int world = blockIdx.x * wpw + wl;
+    if (world >= D.N) return;
+    const int n = W.wn[wl];
+    const bool active = slot < n;
+    const int nobs = active ? n - 1 : 0;
+    const size_t aidx = (size_t)world * M + slot;
+    D.n_observed[aidx] = nobs;
+    if (!ego_out) return;
+    float4* e = reinterpret_cast<float4*>(ego_out + aidx * CAGYM_EGO_WIDTH);
+    if (active) {
+        const double px = W.tpx[a], py = W.tpy[a];
+        e[0] = make_float4((float)W.tdg[a], (float)(W.tgx[a] - px), (float)(W.tgy[a] - py), (float)W.tr[a]);
+        e[1] = make_float4((float)W.the[a], (float)W.th[a], (float)px, (float)py);
+        e[2] = make_float4((float)W.tpref[a], (float)nobs, ST_POLICY(W.tst[a]) == CAGYM_POL_LEARNING ? 1.f : 0.f, 0.f);
+    } else {
+        e[0] = e[1] = e[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+// claim-and-process loop of the observation workers: chunks 0 .. nck-1 are 64 directed pairs each, chunk nck is the
+// scalar-observation store of the agent slots.  Every wave of the workgroup may call it; a wave leaves when the
+// counter has run past the last chunk (every wave reaches that: the counter only grows).
+__device__ __forceinline__ void observation_chunks3(const CagymDev& D, const Lds3& W, const CagymOut& o, int npairs, int M, int MP,
+                                                    int K, int wpw, int worlds_valid, uint32_t inv_m) {
+    const int lane = threadIdx.x & (CAGYM_WAVE - 1);
+    const int nck = (npairs + CAGYM_WAVE - 1) / CAGYM_WAVE;
+    for (;;) {
+        int c = 0;
+        if (lane == 0) c = __hip_atomic_fetch_add(&W.flag[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        c = __builtin_amdgcn_readfirstlane(c);
+        if (c > nck) break;
+        if (c < nck) {
+            if (o.obs_oas) oas_row3(W, o.obs_oas, c * CAGYM_WAVE + lane, npairs, M, MP, K, wpw, worlds_valid, inv_m);
+        } else {
+            ego_obs3(D, W, o.obs_ego, lane, M, wpw, inv_m);
+        }
+    }
+}
+
+__device__ __forceinline__ CagymOut out_slice3(const CagymOut& out, int t, size_t N, size_t NM, int M) {
+    CagymOut o;
+    o.obs_oas = out.obs_oas ? out.obs_oas + (size_t)t * NM * (M - 1) * 10 : nullptr;
+    o.obs_ego = out.obs_ego ? out.obs_ego + (size_t)t * NM * CAGYM_EGO_WIDTH : nullptr;
+    o.laserscan = nullptr;
+    o.reward = out.reward ? out.reward + (size_t)t * NM : nullptr;
+    o.flags = out.flags ? out.flags + (size_t)t * NM : nullptr;
+    o.game_over = out.game_over ? out.game_over + (size_t)t * N : nullptr;
+    return o;
+}
+
+// n_steps env.step() calls of the workgroup's worlds.  ext: external actions of the (single) step or null.
+template <int NT, int MT, int WPWT, bool AUTO_RESET>
+__device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const float* ext, const CagymOut& out, int n_steps,
+                                  bool any_rvo) {
+    constexpr int NWAVES = NT / CAGYM_WAVE;
+    constexpr int GW = MT > 0 && MT <= 5 ? 4 : (MT > 0 && MT <= 10 ? CAGYM_GW10 : 16), NG = NT / GW, NGW = CAGYM_WAVE / GW;
+    const int M = MT ? MT : D.M, K = M - 1, MP = cagym_mp(M);
+    const int AS = cagym_as(M, WPWT);
+    const Lds3 W = carve_lds3(smem, M, AS, NT);
+    LaneCtx C = make_ctx2(D, M, WPWT ? WPWT : CAGYM_WAVE / M);
+    const uint32_t inv_m = (uint32_t)(0x100000000ull / (uint32_t)M) + 1u;
+    const int nagents = C.wpw * M;               // agent slots of this workgroup (<= 64: wave 0)
+    const int npairs = C.wpw * M * M;            // directed pair slots
+    const int nup = C.wpw * (M * (M - 1) / 2);   // unordered pairs
+    const size_t NM = (size_t)D.N * M;
+    float ep_ret = 0.f;
+    int ep_len = 0;
+    STAMP_BEGIN();
+    // ---- prologue: agent records -> LDS; the LP inputs of the first step ---------------------------------------------------
+    {
+        const int tid = threadIdx.x;
+        const bool agent_lane = tid < nagents;
+        if (!agent_lane) C.valid = C.active = false;
+        if (agent_lane) {
+            Agent A = {};
+            if (C.valid) {
+                load_agent(D, A, (size_t)C.world * M + C.slot);
+                if (C.slot == 0) { ep_ret = D.ep_return[C.world]; ep_len = D.ep_len[C.world]; }
+            }
+            lds3_store_agent(W, A, tid);
+            W.tmoved[tid] = 0;
+            W.trvo[tid] = live_rvo(A.st, C.valid && C.active);
+            if (C.wl < C.wpw && C.slot == 0) W.wn[C.wl] = C.valid ? C.n : 0;
+            publish_pref_velocity3(W, tid);
+            // constant entries of the distance / key rows: own slot and the padding
+            W.dsq[tid * MP + C.slot] = INFINITY;
+            W.hit[tid * MP + C.slot] = 0;
+            W.gap[tid * MP + C.slot] = INFINITY;
+            W.keys[tid * MP + C.slot] = -INFINITY;
+            for (int l = M; l < MP; l++) {
+                W.dsq[tid * MP + l] = INFINITY;
+                W.hit[tid * MP + l] = 0;
+                W.gap[tid * MP + l] = INFINITY;
+                W.keys[tid * MP + l] = -INFINITY;
+            }
+        }
+        if (tid < 8) W.flag[tid] = 0;
+        __syncthreads();
+        if (any_rvo) {
+            for (int p = tid; p < nup; p += NT) pair_distances3<MT>(D, W, p, M, MP);
+            __syncthreads();
+            for (int p = tid; p < nup; p += NT) half_planes3<MT>(D, W, p, M, MP, AS);
+        }
+        __syncthreads();
+    }
+    WGTRACE(1);
+#pragma nounroll
+    for (int t = 0; t < n_steps; t++) {
+        int tid = threadIdx.x;
+        // opaque per step: keeps the compiler from hoisting every index derived from tid out of the step loop
+        asm volatile("" : "+v"(tid));
+        const int wave = tid >> 6;
+        const bool agent_lane = tid < nagents;
+        const size_t aidx = (size_t)C.world * M + C.slot;
+        const CagymOut o_prev = out_slice3(out, t > 0 ? t - 1 : 0, (size_t)D.N, NM, M);  // rows of step t-1 (used when t > 0)
+        const CagymOut o = out_slice3(out, t, (size_t)D.N, NM, M);
+#ifndef CAGYM_NO_LAG_PRIORITY
+        // A workgroup whose worlds needed linearProgram3 in the previous step is in a crowd and stays there for many
+        // steps: its step is the long one and the launch ends with the slowest workgroup, so its waves take issue
+        // priority over the co-resident workgroups (which have slack).
+        // Inside a workgroup the observation rows are off the critical chain: their waves run at priority 0, the chain
+        // (linear programs, S1, pair phases) at 1.
+        const bool lagging = __builtin_amdgcn_readfirstlane(W.flag[4]) != 0;
+        if (lagging) __builtin_amdgcn_s_setprio(3);
+        else __builtin_amdgcn_s_setprio(1);
+#endif
+        // ---- phase C: linearProgram2/3 of every busy ego on a GW-lane group (first waves) ------------------------------
+        int lp_waves = 0;
+        if (any_rvo) {
+            int cnt;
+            {
+                const int lane = tid & (CAGYM_WAVE - 1);
+                const bool fl = lane < nagents && W.busy[lane] != 0;
+                const unsigned long long bm = __ballot(fl);
+                cnt = __popcll(bm);
+                if (fl) W.lpk[__popcll(bm & ((1ull << lane) - 1ull))] = lane;
+            }
+            WGTRACE_BUSY(cnt);
+            lp_waves = (cnt + NGW - 1) / NGW;
+            if (lp_waves > NWAVES) lp_waves = NWAVES;
+            const int g = tid / GW, j = tid & (GW - 1);
+            bool worked = false;
+            STAMP(8);  // busy list
+#ifdef CAGYM_STAMPS
+            int dbg[3] = {0, 0, 0};
+#endif
+            for (int base = 0; base < cnt; base += NG) {
+                const int idx = base + g;
+                if (idx < cnt) {
+                    worked = true;
+                    const int a = W.lpk[idx];
+                    const int wl = (int)__umulhi((uint32_t)a, inv_m);
+                    const int n = W.wn[wl];
+                    const int nn = (n - 1) < CAGYM_MAXNB ? (n - 1) : CAGYM_MAXNB;
+                    const float2 pv = W.lpv[a];
+                    const float rad = W.lpr[a];
+                    float vx, vy;
+#ifdef CAGYM_STAMPS
+                    orca_lp_group<GW>(W.sorted, W.lp3 + (tid & ~(GW - 1)), a, j, nn, rad, pv.x, pv.y, vx, vy, AS, &W.flag[3], dbg);
+#else
+                    orca_lp_group<GW>(W.sorted, W.lp3 + (tid & ~(GW - 1)), a, j, nn, rad, pv.x, pv.y, vx, vy, AS, &W.flag[3]);
+#endif
+                    if (j == 0) W.lpc[a] = make_float2(vx, vy);
+                }
+            }
+#ifdef CAGYM_STAMPS
+            if (wave == 0) {  // lockstep trip counts of wave 0: the longest group sets the wave's time
+                int m0 = dbg[0], m1 = dbg[1], m2 = dbg[2];
+                for (int off = 32; off; off >>= 1) {
+                    m0 = max(m0, __shfl_xor(m0, off)); m1 = max(m1, __shfl_xor(m1, off)); m2 = max(m2, __shfl_xor(m2, off));
+                }
+                if (tid == 0 && blockIdx.x == 0) { g_stamps[12] += m0; g_stamps[13] += m1; g_stamps[14] += m2; g_stamps[15] += cnt; }
+            }
+#endif
+            // a wave that solved programs publishes them: LDS operations of one wave complete in order, the release
+            // makes the compiler keep that order
+            if (__builtin_amdgcn_readfirstlane((int)(__ballot(worked) != 0ull)) && (tid & (CAGYM_WAVE - 1)) == 0)
+                __hip_atomic_fetch_add(&W.flag[2], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        STAMP(1);
+        // ---- phase D: wave 0 = S1 (_take_action, env.py:287-340) in registers; the other waves = OAS rows of step t-1 ------
+        Agent A;
+        bool moved = false;
+        const bool s1_lane = agent_lane && C.valid && C.active;
+        if (wave == 0) {
+            if (lp_waves > 0) {  // wait for the other LP waves (bounded: every LP wave increments exactly once per step)
+                while (__hip_atomic_load(&W.flag[2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < lp_waves)
+                    __builtin_amdgcn_s_sleep(1);
+            }
+            STAMP(2);
+            if (s1_lane) {
+                A = lds3_load_agent(W, tid);
+                float a0 = 0.f, a1 = 0.f;
+                if (!(A.st & CAGYM_FLAG_DONE)) {
+                    double d0 = 0.0, d1 = 0.0;
+                    switch (ST_POLICY(A.st)) {
+                        case CAGYM_POL_STATIC: break;
+                        case CAGYM_POL_NONCOOP: d0 = A.pref; d1 = -A.he; break;
+                        case CAGYM_POL_EXTERNAL: case CAGYM_POL_IGMCTS: case CAGYM_POL_GA3C:
+                            if (ext) { d0 = (double)ext[2 * aidx]; d1 = (double)ext[2 * aidx + 1]; }
+                            break;
+                        case CAGYM_POL_LEARNING:
+                            if (ext) { d1 = 4.0 * (2. * (double)ext[2 * aidx + 1] - 1.); d0 = A.pref * (double)ext[2 * aidx]; }
+                            else { d1 = -4.0; }
+                            break;
+                        case CAGYM_POL_CARRL: d0 = 1.0; d1 = carrl_heading(ext ? (int)ext[2 * aidx] : 0); break;
+                        case CAGYM_POL_RVO: {
+                            const float2 v = W.lpc[tid];  // LP result, or the clipped preferred velocity of an ego that needed none
+                            orca_post(A, v.x, v.y, D.dt, d0, d1);
+                            break;
+                        }
+                    }
+                    a0 = (float)d0;
+                    a1 = (float)d1;
+                }
+                moved = take_action<false>(A, a0, a1, D.dt);
+            }
+            STAMP(3);
+        } else if (t > 0) {
+#ifndef CAGYM_NO_LAG_PRIORITY
+            __builtin_amdgcn_s_setprio(0);
+#endif
+            observation_chunks3(D, W, o_prev, npairs, M, MP, K, C.wpw, C.worlds_valid, inv_m);
+#ifndef CAGYM_NO_LAG_PRIORITY
+            if (lagging) __builtin_amdgcn_s_setprio(3);
+            else __builtin_amdgcn_s_setprio(1);
+#endif
+        }
+        __syncthreads();  // rows of step t-1 are out: the moved state may replace the old one
+        if (s1_lane) {
+            lds3_store_moved(W, A, tid);
+            W.tmoved[tid] = moved ? 1 : 0;
+            W.trvo[tid] = live_rvo(A.st, true);
+        } else if (agent_lane) {
+            W.tmoved[tid] = 0;
+        }
+        if (tid == NT - 1) { W.flag[1] = 0; W.flag[2] = 0; W.flag[4] = W.flag[3]; W.flag[3] = 0; }
+        __syncthreads();
+        STAMP(4);
+        // ---- phase A: pair distances, collision tests, OAS sort keys, fp32 squared distances; the last wave first runs
+        //      Dynamics.update_ego_frame of the agents that moved and prepares the next step's LP inputs -------------------
+        if (tid >= NT - CAGYM_WAVE) {
+            const int a = tid - (NT - CAGYM_WAVE);
+            if (a < nagents) {
+                if (W.tmoved[a]) {
+                    Agent E;
+                    E.px = W.tpx[a]; E.py = W.tpy[a]; E.gx = W.tgx[a]; E.gy = W.tgy[a]; E.h = W.th[a];
+                    double prx, pry;
+                    update_ego_frame(E, prx, pry);
+                    W.tdg[a] = E.dg; W.the[a] = E.he; W.tprx[a] = prx; W.tpry[a] = pry;
+                }
+                if (any_rvo) publish_pref_velocity3(W, a);
+            }
+        }
+        for (int p = tid; p < nup; p += NT) pair_distances3<MT>(D, W, p, M, MP);
+        __syncthreads();
+        STAMP(5);
+        // ---- phase B: wave 0 = S2 (_compute_rewards env.py:502-567, _check_which_agents_done :711-738, auto-reset);
+        //      waves 1.. = ORCA half-planes of step t+1 (wave 0 takes the pairs beyond their lanes afterwards) ----------------
+        const bool more = t + 1 < n_steps;
+        const int full_pairs = nup - nup % (NT - CAGYM_WAVE), tail_pairs = nup - full_pairs;
+        if (wave == 0) {
+            if (agent_lane) {
+                float reward = 0.f;
+                Agent S;
+                S.st = W.tst[tid];
+                if (C.valid && C.active) {
+                    S.px = W.tpx[tid]; S.py = W.tpy[tid]; S.r = W.tr[tid];
+                    bool coll_wall = false;
+                    double dmin = INFINITY;
+                    uint32_t hits = 0;
+                    const uint32_t* hrow = reinterpret_cast<const uint32_t*>(W.hit + tid * MP);
+                    const double2* grow = reinterpret_cast<const double2*>(W.gap + tid * MP);
+                    for (int l4 = 0; l4 < MP; l4 += 4) {
+                        hits |= hrow[l4 >> 2];
+                        const double2 g0 = grow[l4 >> 1], g1 = grow[(l4 >> 1) + 1];
+                        dmin = fmin(dmin, fmin(fmin(g0.x, g0.y), fmin(g1.x, g1.y)));
+                    }
+                    const bool coll_agent = hits != 0;
+                    if (D.map_bits) {
+                        int sidx = (int)(((long long)C.world + (long long)C.episode * D.N) % D.S);
+                        if (D.sc_nobst[sidx] > 0)
+                            coll_wall = wall_collision(D.map_bits + (size_t)sidx * CAGYM_MAPD * CAGYM_MAPW, S.px, S.py, S.r);
+                    }
+                    double r = -0.01;
+                    if (S.st & CAGYM_FLAG_AT_GOAL) {
+                        if (!(S.st & CAGYM_FLAG_WAS_AT_GOAL)) r = 3.0;
+                    } else {
+                        if (!(S.st & CAGYM_FLAG_WAS_IN_COLLISION)) {
+                            if (coll_agent) { r = -10.0; S.st |= CAGYM_FLAG_IN_COLLISION; }
+                            else if (coll_wall) { r = -0.25; S.st |= CAGYM_FLAG_IN_COLLISION; }
+                            else if (dmin <= 0.2) r += -0.1 - dmin / 2.;
+                        } else if (S.st & CAGYM_FLAG_RAN_OUT_OF_TIME) {
+                            r += -10.0;
+                        }
+                    }
+                    r = clipd(r, -10.0, 3.0) / (3.0 - (-10.0));
+                    reward = (float)r;
+                    if (S.st & (CAGYM_FLAG_AT_GOAL | CAGYM_FLAG_RAN_OUT_OF_TIME | CAGYM_FLAG_IN_COLLISION)) S.st |= CAGYM_FLAG_DONE;
+                }
+                const bool live = C.valid && C.active;
+                const bool done = !live || (S.st & CAGYM_FLAG_DONE);
+                const uint64_t wm = world_mask64(C);
+                const uint64_t b_done = __ballot(done);
+                const uint64_t b_learn = __ballot(done || ST_POLICY(S.st) != CAGYM_POL_LEARNING);
+                bool go;
+                if (D.go_mode == CAGYM_GO_ALL) go = (b_done & wm) == wm;
+                else if (D.go_mode == CAGYM_GO_LEARNING) go = (b_learn & wm) == wm;
+                else go = C.n > 0 ? ((b_done >> C.base) & 1ull) : true;
+                if (C.valid) {
+                    if (o.reward) o.reward[aidx] = reward;
+                    if (o.flags) o.flags[aidx] = (uint8_t)(S.st & 0xffu);
+                    if (C.slot == 0) {
+                        if (o.game_over) o.game_over[C.world] = go ? 1 : 0;
+                        ep_ret += reward;
+                        ep_len += 1;
+                    }
+                }
+                bool any_reset = false;
+                if (AUTO_RESET) {
+                    const bool rs = C.valid && go;
+                    any_reset = __ballot(rs) != 0ull;
+                    if (any_reset) {
+                        float r0 = rs ? ep_ret : 0.f;
+                        int l0 = rs ? ep_len : 0;
+                        LaneCtx Cr = C;
+                        Cr.valid = rs;
+                        fold_episode_stats(D, Cr, S, r0, l0);
+                        if (rs) {
+                            ep_ret = 0.f;
+                            ep_len = 0;
+                            C.episode += 1;
+                            int sidx = (int)(((long long)C.world + (long long)C.episode * D.N) % D.S);
+                            C.n = D.sc_nagents[sidx];
+                            C.active = C.slot < C.n;
+                            init_agent(D, S, sidx, C.slot, C.active);
+                            lds3_store_agent(W, S, tid);
+                            if (C.slot == 0) W.wn[C.wl] = C.n;
+                        }
+                    }
+                }
+                W.tst[tid] = S.st;
+                if (tid == 0) W.flag[0] = any_reset ? 1 : 0;
+            }
+            // a last partial round of at most one wave of pairs is wave 0's (it is done with S2 before the others finish)
+            if (any_rvo && more && tail_pairs <= CAGYM_WAVE && tid < tail_pairs) half_planes3<MT>(D, W, full_pairs + tid, M, MP, AS);
+        } else if (any_rvo && more) {
+            const int lim = tail_pairs <= CAGYM_WAVE ? full_pairs : nup;
+            for (int p = tid - CAGYM_WAVE; p < lim; p += NT - CAGYM_WAVE) half_planes3<MT>(D, W, p, M, MP, AS);
+        }
+        __syncthreads();
+        STAMP(6);
+        // ---- rare: a world restarted on its next scenario -> everything derived from the old episode is rebuilt -------------
+        if (AUTO_RESET && W.flag[0]) {
+            if (tid >= NT - CAGYM_WAVE) {
+                const int a = tid - (NT - CAGYM_WAVE);
+                if (a < nagents) {
+                    const int wl = (int)__umulhi((uint32_t)a, inv_m);
+                    W.trvo[a] = live_rvo(W.tst[a], (a - wl * M) < W.wn[wl]);
+                    if (any_rvo) publish_pref_velocity3(W, a);
+                }
+            }
+            for (int p = tid; p < nup; p += NT) pair_distances3<MT>(D, W, p, M, MP);
+            __syncthreads();
+            if (any_rvo && more)
+                for (int p = tid; p < nup; p += NT) half_planes3<MT>(D, W, p, M, MP, AS);
+            __syncthreads();
+        }
+        STAMP(7);
+        WGTRACE(2 + t);
+    }
+    // ---- epilogue: observation of the last step on every wave, agent records -> HBM ------------------------------------------
+    {
+        const CagymOut o_last = out_slice3(out, n_steps - 1, (size_t)D.N, NM, M);
+        observation_chunks3(D, W, o_last, npairs, M, MP, K, C.wpw, C.worlds_valid, inv_m);
+        if (C.valid) {
+            const Agent A = lds3_load_agent(W, threadIdx.x);  // own lane's record, written by this lane
+            store_agent(D, A, (size_t)C.world * M + C.slot, true);
+            if (C.slot == 0) {
+                D.ep_return[C.world] = ep_ret;
+                D.ep_len[C.world] = ep_len;
+                D.episode[C.world] = C.episode;
+                D.n_agents[C.world] = C.n;
+            }
+        }
+    }
+}
+
+template <int NT, int MT, int WPWT, bool AUTO_RESET>
+__global__ void __launch_bounds__(NT, (NT <= 256 ? 3 : 2)) k_rollout3(CagymDev D, int n_steps, CagymOut out, int any_rvo) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    WGTRACE(0);
+#ifdef CAGYM_WGTRACE
+    if (threadIdx.x == 0 && blockIdx.x < CAGYM_WGTRACE_MAXWG) g_wgtrace[blockIdx.x * CAGYM_WGTRACE_W + 39] = 0;
+#endif
+    run_steps3<NT, MT, WPWT, AUTO_RESET>(D, smem, nullptr, out, n_steps, any_rvo != 0);
+#ifdef CAGYM_WGTRACE
+    WGTRACE(38);
+    if (threadIdx.x == 0 && blockIdx.x < CAGYM_WGTRACE_MAXWG)
+        g_wgtrace[blockIdx.x * CAGYM_WGTRACE_W + 39] |= __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) & 15u;  // HW_REG_XCC_ID
+#endif
+}
+
+// one step with external actions; the output buffers are NOT sliced (out_slice3 with t = 0 is the identity)
+template <int NT, int MT, int WPWT, bool AUTO_RESET>
+__global__ void __launch_bounds__(NT, (NT <= 256 ? 3 : 2)) k_step3(CagymDev D, const float* ext, CagymOut out, int any_rvo) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    run_steps3<NT, MT, WPWT, AUTO_RESET>(D, smem, ext, out, 1, any_rvo != 0);
+}

@@ -341,9 +341,17 @@ __device__ __forceinline__ bool orca_lp1_group(const float4 ln, const float4 min
 // Agent::computeNewVelocity after the half-planes exist: linearProgram2 on the nn sorted lines of agent column `a`
 // with optimisation velocity (ox, oy), then linearProgram3 from the failing line when infeasible (P: private
 // scratch of >= nn - 1 projected lines).
+#ifdef CAGYM_STAMPS
+#define LPCOUNT(x) ((x)++)
+#else
+#define LPCOUNT(x) do { } while (0)
+#endif
 template <int GW>
 __device__ inline void orca_lp_group(const float4* L, float4* P, int a, int j, int nn, float radius, float ox, float oy,
-                                     float& rx, float& ry, int stride) {
+                                     float& rx, float& ry, int stride, int* lp3_flag = nullptr, int* dbg = nullptr) {
+#ifdef CAGYM_STAMPS
+    int c_lp2 = 0, c_lp3o = 0, c_lp3i = 0;
+#endif
     const int gbase = (threadIdx.x & 63) & ~(GW - 1);
     const uint64_t gbits = (1ull << GW) - 1ull;
     const float4 lj = j < nn ? L[j * stride + a] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -369,6 +377,7 @@ __device__ inline void orca_lp_group(const float4* L, float4* P, int a, int j, i
         const uint32_t m = (uint32_t)((__ballot(v1) >> gbase) & gbits) | ((uint32_t)((__ballot(v2) >> gbase) & 1ull) << GW);
         if (!m) break;
         const int i = __ffs((int)m) - 1;
+        LPCOUNT(c_lp2);
         const float4 li = L[i * stride + a];
         if (!orca_lp1_group<GW>(li, lj, j < i, radius, ox, oy, false, gbase, rx, ry)) {
             fail = i;  // result keeps the value it had before this line (tempResult)
@@ -379,6 +388,7 @@ __device__ inline void orca_lp_group(const float4* L, float4* P, int a, int j, i
     // linearProgram3 (rare).  Same scan-and-jump: the next line at or after `cur` that is violated by more than
     // `distance`, then linearProgram2 (directionOpt) over the projected lines, again by scan-and-jump.
     float distance = 0.0f;
+    if (lp3_flag && fail < nn && j == 0) *lp3_flag = 1;  // this workgroup is in a crowd: its step is the long one
     for (int cur = fail; cur < nn;) {
         const bool w1 = j >= cur && j < nn && detf(lj.z, lj.w, lj.x - rx, lj.y - ry) > distance;
         const bool w2 = extra && GW >= cur && detf(lx.z, lx.w, lx.x - rx, lx.y - ry) > distance;
@@ -386,6 +396,7 @@ __device__ inline void orca_lp_group(const float4* L, float4* P, int a, int j, i
         if (!wm) break;
         const int i = __ffs((int)wm) - 1;
         cur = i + 1;
+        LPCOUNT(c_lp3o);
         const float4 li = L[i * stride + a];
         // projected line of lane j (j < i); `have` = it exists (not "parallel, same direction")
         bool have = false;
@@ -418,6 +429,7 @@ __device__ inline void orca_lp_group(const float4* L, float4* P, int a, int j, i
             if (!um) break;
             const int k = __ffs((int)um) - 1;
             kcur = k + 1;
+            LPCOUNT(c_lp3i);
             const float4 pk = P[k];  // lane k's projected line (same wave: the LDS write above is ordered before this read)
             if (!orca_lp1_group<GW>(pk, pj, j < k && have, radius, px, py, true, gbase, qx, qy)) {
                 failed = true;
@@ -428,4 +440,7 @@ __device__ inline void orca_lp_group(const float4* L, float4* P, int a, int j, i
         else { rx = qx; ry = qy; }
         distance = detf(li.z, li.w, li.x - rx, li.y - ry);
     }
+#ifdef CAGYM_STAMPS
+    if (dbg) { dbg[0] = c_lp2; dbg[1] = c_lp3o; dbg[2] = c_lp3i; }
+#endif
 }

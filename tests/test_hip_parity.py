@@ -181,9 +181,10 @@ def test_full_size_properties():
 
 
 @pytest.mark.parametrize("M,wpw", [(2, None), (4, None), (7, None), (10, "4"), (10, "5"), (13, None), (20, None), (32, None)])
-def test_generation1_and_generation2_kernels_agree_bitwise(M, wpw, monkeypatch):
-    """The phase-split kernels (generation 2, default) share the arithmetic of the one-lane-per-agent
-    kernels (generation 1, CAGYM_KERNEL=v1): trajectories, observations and statistics must be identical."""
+def test_kernel_generations_agree_bitwise(M, wpw, monkeypatch):
+    """The software-pipelined kernels (generation 3, default), the phase-split kernels (generation 2, CAGYM_KERNEL=v2)
+    and the one-lane-per-agent kernels (generation 1, CAGYM_KERNEL=v1) share their arithmetic: trajectories,
+    observations and statistics must be identical."""
     import torch
     N, T = 50, 200
     a6 = scen.random_worlds_fast(3 * N, M, seed=77 + M)
@@ -194,7 +195,7 @@ def test_generation1_and_generation2_kernels_agree_bitwise(M, wpw, monkeypatch):
     res = []
     if wpw:
         monkeypatch.setenv("CAGYM_WPW10", wpw)  # both worlds-per-workgroup variants of the M = 10 kernels
-    for gen in ("v1", "v2"):
+    for gen in ("v1", "v2", "v3"):
         monkeypatch.setenv("CAGYM_KERNEL", gen)
         e = _hip(N=N, M=M, game_over_mode=1, n_scenarios=3 * N)
         e.set_scenario(a6, pol, scen.DYN_UNICYCLE, n_agents=n_agents, coop=np.full((3 * N, M), 0.5))
@@ -205,12 +206,13 @@ def test_generation1_and_generation2_kernels_agree_bitwise(M, wpw, monkeypatch):
         st = {k: v.clone() for k, v in e.env.state().items()}
         res.append(({k: v.clone() for k, v in tr.items()}, st, e.env.obs_oas.clone(), rew.clone()))
         e.env.close()
-    (t1, s1, o1, r1), (t2, s2, o2, r2) = res
-    for k in t1:
-        assert torch.equal(t1[k], t2[k]), k
-    for k in s1:
-        assert torch.equal(s1[k], s2[k]), k
-    assert torch.equal(o1, o2) and torch.equal(r1, r2)
+    (t1, s1, o1, r1) = res[0]
+    for gen, (t2, s2, o2, r2) in zip(("v2", "v3"), res[1:]):
+        for k in t1:
+            assert torch.equal(t1[k], t2[k]), (gen, k)
+        for k in s1:
+            assert torch.equal(s1[k], s2[k]), (gen, k)
+        assert torch.equal(o1, o2) and torch.equal(r1, r2), gen
     assert int(s1["stat_episodes"].sum()) > 0 or M > 20  # 32 crowded agents need more than T steps to all finish
 
 
