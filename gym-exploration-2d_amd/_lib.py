@@ -14,7 +14,8 @@ GO_AGENT0, GO_ALL, GO_LEARNING = 0, 1, 2
 class CagymConfig(C.Structure):
     _fields_ = [("n_worlds", C.c_int32), ("max_agents", C.c_int32), ("n_scenarios", C.c_int32),
                 ("max_obstacles", C.c_int32), ("game_over_mode", C.c_int32), ("collide_with_static", C.c_int32),
-                ("laserscan", C.c_int32), ("device", C.c_int32), ("dt", C.c_double)]
+                ("laserscan", C.c_int32), ("device", C.c_int32), ("dt", C.c_double),
+                ("rvo_max_neighbors", C.c_int32), ("reserved", C.c_int32)]
 
 
 class CagymOutputs(C.Structure):

@@ -28,7 +28,7 @@ GAME_OVER_MODES = {"agent0": _lib.GO_AGENT0, "all": _lib.GO_ALL, "learning": _li
 
 class BatchedCollisionAvoidanceEnv(object):
     def __init__(self, n_worlds, max_agents=10, n_scenarios=None, max_obstacles=0, game_over_mode="agent0",
-                 collide_with_static=False, laserscan=False, device="cuda:0", dt=0.1):
+                 collide_with_static=False, laserscan=False, device="cuda:0", dt=0.1, rvo_max_neighbors=0):
         self.L = _lib.load()
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -41,7 +41,8 @@ class BatchedCollisionAvoidanceEnv(object):
             game_over_mode = GAME_OVER_MODES[game_over_mode]
         idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self.cfg = _lib.CagymConfig(self.N, self.M, self.S, self.Kobs, int(game_over_mode),
-                                    int(bool(collide_with_static)), int(self.laserscan), int(idx), float(dt))
+                                    int(bool(collide_with_static)), int(self.laserscan), int(idx), float(dt),
+                                    int(rvo_max_neighbors), 0)  # rvo_max_neighbors 0 = max_agents (RVOPolicy.py:15)
         self.h = C.c_void_p()
         _lib.check(self.L, None, self.L.cagym_create(C.byref(self.cfg), C.byref(self.h)), "cagym_create")
         N, M, K = self.N, self.M, self.K

@@ -9,7 +9,6 @@
 
 #include "../../include/cagym.h"
 #include "cagym_kernels.h"
-#include "cagym_kernels2.h"
 #include "cagym_kernels3.h"
 #include "cagym_ig.h"
 #include "cagym_ga3c.h"
@@ -32,7 +31,7 @@ struct Env {
     uint32_t* ig_any = nullptr;
     bool ig_ready = false;
     int any_rvo = 1;
-    int generation = 3;  // CAGYM_KERNEL=v1 / v2 select the older kernel generations (bitwise A/B only)
+    int generation = 3;  // CAGYM_KERNEL=v1 selects the one-lane-per-agent kernels (bitwise A/B only)
     int wpw10 = 5;       // worlds per workgroup of the M = 10 kernels (4 while all workgroups are co-resident)
 };
 
@@ -127,11 +126,6 @@ inline int n_wg2(const Env* e) {
     const int wpw = wpw_spec(e) ? wpw_spec(e) : CAGYM_WAVE / M;
     return (e->cfg.n_worlds + wpw - 1) / wpw;
 }
-inline size_t lds2_bytes(const Env* e) {
-    const int M = e->cfg.max_agents;
-    return cagym_lds2_bytes(M, cagym_as(M, wpw_spec(e)));
-}
-
 inline size_t lds3_bytes(const Env* e) {
     const int M = e->cfg.max_agents;
     return cagym_lds3_bytes(M, cagym_as(M, wpw_spec(e)), spec2(e).nt);
@@ -143,13 +137,6 @@ inline int n_waves(const Env* e) {
 }
 
 template <int NT, int MT, int WP>
-void set_lds_attr2(int lds2) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<NT, MT, WP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_step2<NT, MT, WP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<NT, MT, WP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout2<NT, MT, WP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-}
-template <int NT, int MT, int WP>
 void set_lds_attr3(int lds3) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_step3<NT, MT, WP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds3);
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_step3<NT, MT, WP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds3);
@@ -157,7 +144,7 @@ void set_lds_attr3(int lds3) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout3<NT, MT, WP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds3);
 }
 
-// the one place that maps a handle to its generation-2 kernel instantiation
+// the one place that maps a handle to its kernel instantiation
 #define CAGYM_DISPATCH2(e, CALL)                                   \
     do {                                                           \
         const Spec2 _s = spec2(e);                                 \
@@ -188,6 +175,7 @@ int cagym_create(const cagym_config* cfg, void** env_out) {
         return fail(nullptr, CAGYM_E_UNSUPPORTED, "max_agents must be in [2, 32] (a world may not straddle a wavefront)");
     if (cfg->n_scenarios < cfg->n_worlds) return fail(nullptr, CAGYM_E_INVALID, "n_scenarios must be >= n_worlds");
     if (cfg->max_obstacles < 0 || !(cfg->dt > 0)) return fail(nullptr, CAGYM_E_INVALID, "bad max_obstacles / dt");
+    if (cfg->rvo_max_neighbors < 0) return fail(nullptr, CAGYM_E_INVALID, "rvo_max_neighbors must be >= 0 (0 = max_agents)");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
         return fail(nullptr, CAGYM_E_NODEVICE, "no HIP device: libcagym_hip has no CPU fallback");
@@ -205,6 +193,8 @@ int cagym_create(const cagym_config* cfg, void** env_out) {
     D.N = (int)N; D.M = (int)M; D.S = (int)S; D.Kobs = cfg->max_obstacles;
     D.go_mode = cfg->game_over_mode; D.collide_static = cfg->collide_with_static; D.laserscan = cfg->laserscan;
     D.dt = cfg->dt;
+    D.maxnb = cfg->rvo_max_neighbors > 0 ? cfg->rvo_max_neighbors : (int)M;  // RVOPolicy.py:15: Config.MAX_NUM_AGENTS_IN_ENVIRONMENT
+    if (D.maxnb > (int)M - 1) D.maxnb = (int)M - 1;                            // there are at most M - 1 other agents
     int rc = CAGYM_OK;
     double* d6 = nullptr; double* dcoop = nullptr;
     int32_t *dpol = nullptr, *ddyn = nullptr, *dna = nullptr, *dno = nullptr;
@@ -240,7 +230,6 @@ int cagym_create(const cagym_config* cfg, void** env_out) {
     {
         const char* g = getenv("CAGYM_KERNEL");
         if (g && (!strcmp(g, "v1") || !strcmp(g, "1"))) e->generation = 1;
-        if (g && (!strcmp(g, "v2") || !strcmp(g, "2"))) e->generation = 2;
         {
             hipDeviceProp_t prop;
             int cus = 256;
@@ -250,10 +239,9 @@ int cagym_create(const cagym_config* cfg, void** env_out) {
             const char* w = getenv("CAGYM_WPW10");  // diagnostics
             if (w && (w[0] == '4' || w[0] == '5')) e->wpw10 = w[0] - '0';
         }
-        int lds2 = (int)lds2_bytes(e), lds3 = (int)lds3_bytes(e);
-        if (e->generation == 3 && lds3 > 160 * 1024) e->generation = 2;
-        if (e->generation == 2 && lds2 > 160 * 1024) e->generation = 1;
-#define SETATTR(NT, MT, WP) set_lds_attr2<NT, MT, WP>(lds2); set_lds_attr3<NT, MT, WP>(lds3)
+        int lds3 = (int)lds3_bytes(e);
+        if (e->generation == 3 && lds3 > 160 * 1024) e->generation = 1;
+#define SETATTR(NT, MT, WP) set_lds_attr3<NT, MT, WP>(lds3)
         CAGYM_DISPATCH2(e, SETATTR);
 #undef SETATTR
     }
@@ -411,11 +399,6 @@ int cagym_step(void* env, const float* ext_actions, const cagym_outputs* out, vo
 #define STEP3(NT, MT, WP) hipLaunchKernelGGL((k_step3<NT, MT, WP, false>), dim3(n_wg2(e)), dim3(NT), lds3, st, e->D, ext_actions, o, e->any_rvo)
         CAGYM_DISPATCH2(e, STEP3);
 #undef STEP3
-    } else if (e->generation == 2) {
-        const size_t lds2 = lds2_bytes(e);
-#define STEP2(NT, MT, WP) hipLaunchKernelGGL((k_step2<NT, MT, WP, false>), dim3(n_wg2(e)), dim3(NT), lds2, st, e->D, ext_actions, o, e->any_rvo)
-        CAGYM_DISPATCH2(e, STEP2);
-#undef STEP2
     } else
     hipLaunchKernelGGL(k_step, dim3(n_waves(e)), dim3(64), cagym_lds_bytes(e->cfg.max_agents), st, e->D, ext_actions, o);
     HIPCHK(e, hipGetLastError());
@@ -435,13 +418,8 @@ int cagym_step_autoreset(void* env, const float* ext_actions, const cagym_output
 #define STEP3(NT, MT, WP) hipLaunchKernelGGL((k_step3<NT, MT, WP, true>), dim3(n_wg2(e)), dim3(NT), lds3, st, e->D, ext_actions, o, e->any_rvo)
         CAGYM_DISPATCH2(e, STEP3);
 #undef STEP3
-    } else if (e->generation == 2) {
-        const size_t lds2 = lds2_bytes(e);
-#define STEP2(NT, MT, WP) hipLaunchKernelGGL((k_step2<NT, MT, WP, true>), dim3(n_wg2(e)), dim3(NT), lds2, st, e->D, ext_actions, o, e->any_rvo)
-        CAGYM_DISPATCH2(e, STEP2);
-#undef STEP2
     } else
-        return fail(e, CAGYM_E_UNSUPPORTED, "cagym_step_autoreset needs the generation-2 or -3 kernels");
+        return fail(e, CAGYM_E_UNSUPPORTED, "cagym_step_autoreset needs the generation-3 kernels");
     HIPCHK(e, hipGetLastError());
     if (e->cfg.laserscan && o.laserscan) return cagym_laserscan(env, o.laserscan, stream);
     return CAGYM_OK;
@@ -468,16 +446,6 @@ int cagym_rollout(void* env, int n_steps, int auto_reset, const cagym_outputs* o
     } while (0)
         CAGYM_DISPATCH2(e, ROLL3);
 #undef ROLL3
-    } else if (e->generation == 2) {
-        const size_t lds2 = lds2_bytes(e);
-        const dim3 g(n_wg2(e));
-#define ROLL2(NT, MT, WP)                                                                                              \
-    do {                                                                                                           \
-        if (auto_reset) hipLaunchKernelGGL((k_rollout2<NT, MT, WP, true>), g, dim3(NT), lds2, st, e->D, n_steps, o, e->any_rvo); \
-        else hipLaunchKernelGGL((k_rollout2<NT, MT, WP, false>), g, dim3(NT), lds2, st, e->D, n_steps, o, e->any_rvo);         \
-    } while (0)
-        CAGYM_DISPATCH2(e, ROLL2);
-#undef ROLL2
     } else if (auto_reset)
         hipLaunchKernelGGL(k_rollout<true>, dim3(n_waves(e)), dim3(64), lds, st, e->D, n_steps, o);
     else
@@ -489,7 +457,7 @@ int cagym_rollout(void* env, int n_steps, int auto_reset, const cagym_outputs* o
 int cagym_kernel_name(void* env, int rollout, int auto_reset, char* buf, int buf_len) {
     Env* e = reinterpret_cast<Env*>(env);
     if (!e || !buf || buf_len < 1) return fail(e, CAGYM_E_INVALID, "bad arguments");
-    if (e->generation >= 2) {
+    if (e->generation == 3) {
         const Spec2 sp = spec2(e);
         snprintf(buf, (size_t)buf_len, "%s%d<%d, %d, %d, %s>", rollout ? "k_rollout" : "k_step", e->generation, sp.nt, sp.mt,
                  sp.wpw, auto_reset ? "true" : "false");

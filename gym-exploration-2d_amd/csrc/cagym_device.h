@@ -17,13 +17,14 @@
 #define CAGYM_WAVE 64
 #define CAGYM_MAPD 300
 #define CAGYM_MAPW 10 /* u32 words per raster row (320 bits) */
-#define CAGYM_MAXNB 10 /* RVO maxNeighbors (policies/RVOPolicy.py:14) */
+#define CAGYM_MAXNB_CAP 31 /* most other agents a world can hold (max_agents <= 32) */
 
 static constexpr double kPi = 3.141592653589793;
 
 // Everything the kernels need, passed by value (device pointers + scalars).
 struct CagymDev {
     int N, M, S, Kobs, go_mode, collide_static, laserscan;
+    int maxnb;  // RVO maxNeighbors (policies/RVOPolicy.py:15,25), 1 .. M - 1
     double dt;
     // scenario pool [S, ...]
     const double* sc_agents6;

@@ -18,14 +18,15 @@ struct WaveLds {
     uint32_t* tst;                        // status words [64]
     double* keys;                         // OAS sort keys [(M-1)][64]
     float* oas;                           // OAS staging [64*(M-1)*10] floats   } union
-    float4* lines;                        // ORCA lines [2][CAGYM_MAXNB][64]     }
+    float4* lines;                        // ORCA lines [2][M - 1][64]           }
 };
 
+// ORCA line arrays of generation 1: [2][M - 1][64] (every other agent may be a neighbour: maxNeighbors <= M - 1)
 __host__ __device__ inline size_t cagym_lds_bytes(int M) {
     size_t tile = 5 * 64 * 8 + 64 * 4;
     size_t keys = (size_t)(M - 1) * 64 * 8;
     size_t oas = (size_t)64 * (M - 1) * 10 * 4;
-    size_t lines = (size_t)2 * CAGYM_MAXNB * 64 * 16;
+    size_t lines = (size_t)2 * (M - 1) * 64 * 16;
     return tile + keys + (oas > lines ? oas : lines);
 }
 
@@ -40,7 +41,7 @@ __device__ __forceinline__ WaveLds carve_lds(unsigned char* smem, int M) {
     unsigned char* p = reinterpret_cast<unsigned char*>(W.keys + (size_t)(M - 1) * 64);
     W.oas = reinterpret_cast<float*>(p);
     W.lines = reinterpret_cast<float4*>(p);
-    size_t oas = (size_t)64 * (M - 1) * 10 * 4, lines = (size_t)2 * CAGYM_MAXNB * 64 * 16;
+    size_t oas = (size_t)64 * (M - 1) * 10 * 4, lines = (size_t)2 * (M - 1) * 64 * 16;
     W.tst = reinterpret_cast<uint32_t*>(p + (oas > lines ? oas : lines));
     return W;
 }
@@ -203,7 +204,7 @@ __device__ inline void step_core(const CagymDev& D, const WaveLds& W, LaneCtx& C
             case CAGYM_POL_CARRL: d0 = 1.0; d1 = carrl_heading(ext ? (int)ext[2 * aidx] : 0); break;
             case CAGYM_POL_RVO: {
                 NbrTile T{W.tpx, W.tpy, W.tvx, W.tvy, W.tr};
-                orca_action(T, W.lines, W.lines + CAGYM_MAXNB * 64, lane, C.base, C.n, C.slot, A, D.dt, d0, d1);
+                orca_action(T, W.lines, W.lines + (M - 1) * 64, lane, C.base, C.n, C.slot, A, D.dt, D.maxnb, d0, d1);
                 break;
             }
         }

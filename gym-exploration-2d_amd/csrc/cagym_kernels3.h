@@ -16,10 +16,121 @@
 //   (rare)    a world was reset in S2: keys, distances, preferred velocities and half-planes are rebuilt in two extra phases
 //
 // Wave 0 waits for the other LP waves on an LDS counter (release/acquire at workgroup scope), not on a barrier, so the
-// row workers never stop between C and D.  Arithmetic is shared with generations 1 and 2 (cagym_device.h, cagym_orca.h):
-// all three produce bit-identical results (tests/test_hip_parity.py).
+// row workers never stop between C and D.  Arithmetic is shared with generation 1 (cagym_device.h, cagym_orca.h):
+// both produce bit-identical results (tests/test_hip_parity.py); generation 2 (phase-split, one barrier-separated phase after
+// the other) was retired once generation 3 reproduced it bit for bit.
 #pragma once
-#include "cagym_kernels2.h"
+#include "cagym_kernels.h"
+
+// Diagnostic build only (-DCAGYM_STAMPS, never the shipped library): thread 0 of workgroup 0 accumulates
+// s_memtime deltas per phase into g_stamps; read back with cagym_debug_stamps().  The stamp values leave
+// the kernel only through this buffer and feed no output.
+#ifdef CAGYM_STAMPS
+__device__ unsigned long long g_stamps[16];
+#define STAMP(i)                                                                  \
+    do {                                                                          \
+        if (threadIdx.x == 0 && blockIdx.x == 0) {                                \
+            unsigned long long _t = __builtin_amdgcn_s_memtime();                 \
+            g_stamps[i] += _t - stamp_prev;                                       \
+            stamp_prev = _t;                                                      \
+        }                                                                         \
+    } while (0)
+#define STAMP_BEGIN() unsigned long long stamp_prev = __builtin_amdgcn_s_memtime()
+#else
+#define STAMP(i) do { } while (0)
+#define STAMP_BEGIN() do { } while (0)
+#endif
+
+// Second diagnostic build (-DCAGYM_WGTRACE, tools/launch_cost.py): thread 0 of EVERY workgroup records the 100 MHz
+// s_memrealtime clock at kernel entry, after the prologue, after each of the first 36 steps and at exit, plus its XCC id,
+// into g_wgtrace (read back with cagym_debug_wgtrace()).  Same rule: the values feed no output.
+#ifdef CAGYM_WGTRACE
+#define CAGYM_WGTRACE_MAXWG 4096
+#define CAGYM_WGTRACE_W 40
+__device__ unsigned long long g_wgtrace[CAGYM_WGTRACE_MAXWG * CAGYM_WGTRACE_W];
+#define WGTRACE(slot)                                                                                       \
+    do {                                                                                                    \
+        if (threadIdx.x == 0 && blockIdx.x < CAGYM_WGTRACE_MAXWG && (slot) < CAGYM_WGTRACE_W)               \
+            g_wgtrace[blockIdx.x * CAGYM_WGTRACE_W + (slot)] = __builtin_amdgcn_s_memrealtime();            \
+    } while (0)
+#define WGTRACE_BUSY(cnt)                                                                                   \
+    do {                                                                                                    \
+        if (threadIdx.x == 0 && blockIdx.x < CAGYM_WGTRACE_MAXWG)                                           \
+            g_wgtrace[blockIdx.x * CAGYM_WGTRACE_W + 39] += (unsigned long long)(cnt) << 8;                 \
+    } while (0)
+#else
+#define WGTRACE(slot) do { } while (0)
+#define WGTRACE_BUSY(cnt) do { } while (0)
+#endif
+
+#ifndef CAGYM_GW10
+#define CAGYM_GW10 8  // lanes per ORCA LP group when M <= 10 (nn <= 9 half-planes)
+#endif
+
+__host__ __device__ inline size_t a16(size_t x) { return (x + 15) & ~(size_t)15; }
+__host__ __device__ inline int cagym_mp(int M) { return (M + 3) & ~3; }
+
+// AS = agent slots per workgroup (worlds per workgroup x M, rounded up to 4); 64 when a full wave is used
+__host__ __device__ inline int cagym_as(int M, int wpw) { return wpw > 0 ? ((wpw * M + 3) & ~3) : 64; }
+
+
+__device__ __forceinline__ LaneCtx make_ctx2(const CagymDev& D, int M, int wpw) {
+    LaneCtx C;
+    C.lane = threadIdx.x;
+    C.wpw = wpw;
+    C.wl = C.lane / M;
+    C.slot = C.lane - C.wl * M;
+    C.base = C.wl * M;
+    C.world = blockIdx.x * C.wpw + C.wl;
+    int rem = D.N - (int)blockIdx.x * C.wpw;
+    C.worlds_valid = rem < C.wpw ? rem : C.wpw;
+    C.valid = C.wl < C.wpw && C.world < D.N;
+    C.n = C.valid ? D.n_agents[C.world] : 0;
+    C.episode = C.valid ? D.episode[C.world] : 0;
+    C.active = C.valid && C.slot < C.n;
+    return C;
+}
+
+// pair slot p = agent * M + j  ->  (agent lane a, neighbour slot j, world_local wl, agent slot sl)
+struct PairIdx {
+    int a, j, wl, sl;
+};
+__device__ __forceinline__ PairIdx pair_of(int p, int M, uint32_t inv_m) {
+    PairIdx q;
+    q.a = (int)__umulhi((uint32_t)p, inv_m);  // p / M for p < 2^16 (inv_m = 2^32 / M + 1)
+    q.j = p - q.a * M;
+    q.wl = (int)__umulhi((uint32_t)q.a, inv_m);
+    q.sl = q.a - q.wl * M;
+    return q;
+}
+
+// Unordered pairs of M slots by circular difference: (i, i+k mod M) for k = 1..(M-1)/2, plus the M/2 diameters
+// when M is even.  p -> (world of the workgroup, i, j) with compile-time divisors only.
+struct UPair {
+    int wl, i, j;
+};
+template <int MT>
+struct UnorderedPairs {
+    static constexpr int N = MT > 0 ? MT * (MT - 1) / 2 : 1;
+    static constexpr int H = MT > 0 ? (MT - 1) / 2 : 1;
+    static constexpr int MM = MT > 0 ? MT : 1;
+    __device__ static __forceinline__ UPair of(int p) {
+        UPair q;
+        q.wl = p / N;
+        const int u = p - q.wl * N;
+        if (u < MM * H) {
+            const int k = u / MM;
+            q.i = u - k * MM;
+            q.j = q.i + k + 1;
+            if (q.j >= MM) q.j -= MM;
+        } else {
+            q.i = u - MM * H;
+            q.j = q.i + MM / 2;
+        }
+        return q;
+    }
+};
+
 
 struct Lds3 {
     double *tpx, *tpy, *tvx, *tvy, *tr, *tprx, *tpry;
@@ -38,8 +149,8 @@ struct Lds3 {
     int* lpk;      // [AS] compact list of the busy egos
     int* busy;     // [AS] some half-plane of the ego is violated by its LP start
     float* dsq;      // [AS*MP]       squared centre distance ego->slot, fp32 as RVO2 (+inf = no such neighbour)
-    float4* sorted;  // [MAXNB][AS]   half-planes nearest-first
-    float4* lp3;     // [NT]          linearProgram3 scratch, GW entries per LP group
+    float4* sorted;  // [M - 1][AS]   half-planes nearest-first (maxNeighbors <= M - 1 of them are used)
+    float4* lp3;     // [2 NT]        linearProgram3 scratch, 2 GW entries per LP group
     double* keys;    // [AS*MP]       OAS sort key (-inf = not observed)
     double* gap;     // [AS*MP]       d - (r_i + r_j) for the lower index of a pair, else +inf
     uint8_t* hit;    // [AS*MP]       pair collides
@@ -50,7 +161,7 @@ __host__ __device__ inline size_t cagym_lds3_head(int AS) {
 }
 __host__ __device__ inline size_t cagym_lds3_bytes(int M, int AS, int NT) {
     const size_t MP = cagym_mp(M);
-    return a16(cagym_lds3_head(AS)) + a16(AS * MP * 4) + (size_t)CAGYM_MAXNB * AS * 16 + (size_t)NT * 16 + 2 * AS * MP * 8 + a16(AS * MP);
+    return a16(cagym_lds3_head(AS)) + a16(AS * MP * 4) + (size_t)(M - 1) * AS * 16 + (size_t)2 * NT * 16 + 2 * AS * MP * 8 + a16(AS * MP);
 }
 
 __device__ __forceinline__ Lds3 carve_lds3(unsigned char* smem, int M, int AS, int NT) {
@@ -78,9 +189,9 @@ __device__ __forceinline__ Lds3 carve_lds3(unsigned char* smem, int M, int AS, i
     W.dsq = reinterpret_cast<float*>(u);
     u += a16(AS * MP * 4);
     W.sorted = reinterpret_cast<float4*>(u);
-    u += (size_t)CAGYM_MAXNB * AS * 16;
+    u += (size_t)(M - 1) * AS * 16;
     W.lp3 = reinterpret_cast<float4*>(u);
-    u += (size_t)NT * 16;
+    u += (size_t)2 * NT * 16;
     W.keys = reinterpret_cast<double*>(u);
     W.gap = W.keys + AS * MP;
     W.hit = reinterpret_cast<uint8_t*>(W.gap + AS * MP);
@@ -91,6 +202,15 @@ __device__ __forceinline__ void lds3_store_moved(const Lds3& W, const Agent& A, 
     W.tpx[lane] = A.px; W.tpy[lane] = A.py; W.tvx[lane] = A.vx; W.tvy[lane] = A.vy;
     W.tprx[lane] = A.prx; W.tpry[lane] = A.pry;
     W.th[lane] = A.h; W.the[lane] = A.he; W.tdg[lane] = A.dg; W.ttrem[lane] = A.trem; W.tt[lane] = A.t;
+    W.tspeed[lane] = A.speed; W.tdh[lane] = A.dh; W.taux0[lane] = A.aux0; W.taux1[lane] = A.aux1;
+    W.tact[lane] = make_float2(A.a0, A.a1);
+    W.tst[lane] = A.st;
+    W.tstep[lane] = A.step;
+}
+// what S1 (take_action<false>) changes: the ego frame (prx, pry, he, dg) is phase A's, the constants never change
+__device__ __forceinline__ void lds3_store_s1(const Lds3& W, const Agent& A, int lane) {
+    W.tpx[lane] = A.px; W.tpy[lane] = A.py; W.tvx[lane] = A.vx; W.tvy[lane] = A.vy;
+    W.th[lane] = A.h; W.ttrem[lane] = A.trem; W.tt[lane] = A.t;
     W.tspeed[lane] = A.speed; W.tdh[lane] = A.dh; W.taux0[lane] = A.aux0; W.taux1[lane] = A.aux1;
     W.tact[lane] = make_float2(A.a0, A.a1);
     W.tst[lane] = A.st;
@@ -245,7 +365,7 @@ __device__ __forceinline__ void half_planes3(const CagymDev& D, const Lds3& W, i
         const float2 s0 = W.lpc[a];
         if (detf(ln.z, ln.w, ln.x - s0.x, ln.y - s0.y) > 0.0f) W.busy[a] = 1;
         const int rank = neighbour_rank3<MT>(W, a, q.j, g.d2, MP);
-        if (rank < CAGYM_MAXNB) W.sorted[rank * AS + a] = ln;
+        if (rank < D.maxnb) W.sorted[rank * AS + a] = ln;
     }
     if (on_b) {
         const float c = W.tcoop[b];
@@ -253,7 +373,7 @@ __device__ __forceinline__ void half_planes3(const CagymDev& D, const Lds3& W, i
         const float2 s0 = W.lpc[b];
         if (detf(ln.z, ln.w, ln.x - s0.x, ln.y - s0.y) > 0.0f) W.busy[b] = 1;
         const int rank = neighbour_rank3<MT>(W, b, q.i, g.d2, MP);
-        if (rank < CAGYM_MAXNB) W.sorted[rank * AS + b] = ln;
+        if (rank < D.maxnb) W.sorted[rank * AS + b] = ln;
     }
 }
 
@@ -362,6 +482,7 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
                                   bool any_rvo) {
     constexpr int NWAVES = NT / CAGYM_WAVE;
     constexpr int GW = MT > 0 && MT <= 5 ? 4 : (MT > 0 && MT <= 10 ? CAGYM_GW10 : 16), NG = NT / GW, NGW = CAGYM_WAVE / GW;
+    constexpr bool TWO = !(MT > 0 && MT - 1 <= GW + 1);  // more than GW + 1 half-planes possible: two per lane of an LP group
     const int M = MT ? MT : D.M, K = M - 1, MP = cagym_mp(M);
     const int AS = cagym_as(M, WPWT);
     const Lds3 W = carve_lds3(smem, M, AS, NT);
@@ -459,14 +580,14 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
                     const int a = W.lpk[idx];
                     const int wl = (int)__umulhi((uint32_t)a, inv_m);
                     const int n = W.wn[wl];
-                    const int nn = (n - 1) < CAGYM_MAXNB ? (n - 1) : CAGYM_MAXNB;
+                    const int nn = (n - 1) < D.maxnb ? (n - 1) : D.maxnb;
                     const float2 pv = W.lpv[a];
                     const float rad = W.lpr[a];
                     float vx, vy;
 #ifdef CAGYM_STAMPS
-                    orca_lp_group<GW>(W.sorted, W.lp3 + (tid & ~(GW - 1)), a, j, nn, rad, pv.x, pv.y, vx, vy, AS, &W.flag[3], dbg);
+                    orca_lp_group<GW, TWO>(W.sorted, W.lp3 + 2 * (tid & ~(GW - 1)), a, j, nn, rad, pv.x, pv.y, vx, vy, AS, &W.flag[3], dbg);
 #else
-                    orca_lp_group<GW>(W.sorted, W.lp3 + (tid & ~(GW - 1)), a, j, nn, rad, pv.x, pv.y, vx, vy, AS, &W.flag[3]);
+                    orca_lp_group<GW, TWO>(W.sorted, W.lp3 + 2 * (tid & ~(GW - 1)), a, j, nn, rad, pv.x, pv.y, vx, vy, AS, &W.flag[3]);
 #endif
                     if (j == 0) W.lpc[a] = make_float2(vx, vy);
                 }
@@ -536,7 +657,7 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
         }
         __syncthreads();  // rows of step t-1 are out: the moved state may replace the old one
         if (s1_lane) {
-            lds3_store_moved(W, A, tid);
+            lds3_store_s1(W, A, tid);
             W.tmoved[tid] = moved ? 1 : 0;
             W.trvo[tid] = live_rvo(A.st, true);
         } else if (agent_lane) {
@@ -694,8 +815,12 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
     }
 }
 
+// waves per SIMD the register budget is held to: 4 workgroups per CU for the specialisations whose LP groups hold one
+// half-plane per lane (4096 worlds x 10 agents = 1024 workgroups = 4 per CU must be co-resident), 3 otherwise
+__host__ __device__ constexpr int cagym_min_waves3(int NT, int MT) { return NT > 256 ? 2 : ((MT > 0 && MT <= 10) ? 4 : 3); }
+
 template <int NT, int MT, int WPWT, bool AUTO_RESET>
-__global__ void __launch_bounds__(NT, (NT <= 256 ? 3 : 2)) k_rollout3(CagymDev D, int n_steps, CagymOut out, int any_rvo) {
+__global__ void __launch_bounds__(NT, cagym_min_waves3(NT, MT)) k_rollout3(CagymDev D, int n_steps, CagymOut out, int any_rvo) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     WGTRACE(0);
 #ifdef CAGYM_WGTRACE
@@ -711,7 +836,7 @@ __global__ void __launch_bounds__(NT, (NT <= 256 ? 3 : 2)) k_rollout3(CagymDev D
 
 // one step with external actions; the output buffers are NOT sliced (out_slice3 with t = 0 is the identity)
 template <int NT, int MT, int WPWT, bool AUTO_RESET>
-__global__ void __launch_bounds__(NT, (NT <= 256 ? 3 : 2)) k_step3(CagymDev D, const float* ext, CagymOut out, int any_rvo) {
+__global__ void __launch_bounds__(NT, cagym_min_waves3(NT, MT)) k_step3(CagymDev D, const float* ext, CagymOut out, int any_rvo) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     run_steps3<NT, MT, WPWT, AUTO_RESET>(D, smem, ext, out, 1, any_rvo != 0);
 }

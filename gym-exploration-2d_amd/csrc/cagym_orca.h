@@ -236,13 +236,13 @@ __device__ inline void orca_solve(const float4* L, float4* P, int lane, int nn, 
 }
 
 // RVOPolicy.find_next_action for the agent on `lane`; base = first lane of its world, n = agents in
-// the world, i = own slot.  L, P: LDS line arrays [CAGYM_MAXNB][64].  Returns (speed, delta_heading).
+// the world, i = own slot.  L, P: LDS line arrays [maxnb][64].  Returns (speed, delta_heading).
 __device__ inline void orca_action(const NbrTile& T, float4* L, float4* P, int lane, int base, int n, int i,
-                                   const Agent& A, double dt, double& out_speed, double& out_dh) {
+                                   const Agent& A, double dt, int maxnb, double& out_speed, double& out_dh) {
     const OrcaEgo E = orca_ego(A, dt);
-    // neighbour selection: nearest first, ties in index order, at most 10 (Agent::insertAgentNeighbor).
-    // rank by counting == the insertion sort's result; ranks >= 10 are dropped.
-    int nn = (n - 1) < CAGYM_MAXNB ? (n - 1) : CAGYM_MAXNB;
+    // neighbour selection: nearest first, ties in index order, at most maxNeighbors (Agent::insertAgentNeighbor).
+    // rank by counting == the insertion sort's result; ranks >= maxNeighbors are dropped.
+    int nn = (n - 1) < maxnb ? (n - 1) : maxnb;
     for (int j = 0; j < n; j++) {
         if (j == i) continue;
         float ox = (float)T.px[base + j], oy = (float)T.py[base + j];
@@ -255,7 +255,7 @@ __device__ inline void orca_action(const NbrTile& T, float4* L, float4* P, int l
             float qsq = qx * qx + qy * qy;
             rank += (qsq < dsq) || (qsq == dsq && l < j);
         }
-        if (rank >= CAGYM_MAXNB) continue;
+        if (rank >= maxnb) continue;
         L[rank * CAGYM_WAVE + lane] = orca_line(E.px, E.py, E.vx, E.vy, E.r, E.c, E.time_step, T.px[base + j],
                                                 T.py[base + j], T.vx[base + j], T.vy[base + j], T.r[base + j]);
     }
@@ -300,27 +300,43 @@ __device__ __forceinline__ float grp_min(float v) {
     return dpp_min_quad1(v);
 }
 
-// linearProgram1 on the group: half-plane `ln` against the lanes' own lines (`mine`, taking part when `take`).
-// dir_opt as in RVO2.  Returns false when infeasible (result untouched).
-template <int GW>
-__device__ __forceinline__ bool orca_lp1_group(const float4 ln, const float4 mine, bool take, float radius, float ox,
-                                               float oy, bool dir_opt, int gbase, float& rx, float& ry) {
+// linearProgram1 on the group: half-plane `ln` against the lanes' own lines (`m0` taking part when `take0`, the lane's
+// second line `m1` when `take1`).  dir_opt as in RVO2.  Returns false when infeasible (result untouched).
+__device__ __forceinline__ void orca_clip_by(const float4 ln, const float4 mine, float& ltl, float& ltr) {
+    const float den = detf(ln.z, ln.w, mine.z, mine.w);
+    const float num = detf(mine.z, mine.w, ln.x - mine.x, ln.y - mine.y);
+    if (fabsf(den) <= RVO_EPS) {
+        if (num < 0.0f) ltl = INFINITY;  // "parallel and outside": forces tLeft > tRight below, i.e. infeasible
+    } else {
+        const float t = num / den;
+        if (den >= 0.0f) ltr = fminf(ltr, t);
+        else ltl = fmaxf(ltl, t);
+    }
+}
+template <int GW, bool TWO>
+__device__ __forceinline__ bool orca_lp1_group(const float4 ln, const float4 m0, bool take0, const float4 m1, bool take1,
+                                               float radius, float ox, float oy, bool dir_opt, float& rx, float& ry) {
     const float dot = ln.x * ln.z + ln.y * ln.w;
     const float disc = dot * dot + radius * radius - (ln.x * ln.x + ln.y * ln.y);
     if (disc < 0.0f) return false;
     const float sq = sqrtf(disc);
     float tl = -dot - sq, tr = -dot + sq;
     float ltl = -INFINITY, ltr = INFINITY;
-    if (take) {
-        const float den = detf(ln.z, ln.w, mine.z, mine.w);
-        const float num = detf(mine.z, mine.w, ln.x - mine.x, ln.y - mine.y);
-        if (fabsf(den) <= RVO_EPS) {
-            if (num < 0.0f) ltl = INFINITY;  // "parallel and outside": forces tLeft > tRight below, i.e. infeasible
-        } else {
-            const float t = num / den;
-            if (den >= 0.0f) ltr = t;
-            else ltl = t;
+    if (!TWO) {
+        if (take0) {  // one candidate per lane: plain selects
+            const float den = detf(ln.z, ln.w, m0.z, m0.w);
+            const float num = detf(m0.z, m0.w, ln.x - m0.x, ln.y - m0.y);
+            if (fabsf(den) <= RVO_EPS) {
+                if (num < 0.0f) ltl = INFINITY;  // "parallel and outside": forces tLeft > tRight below, i.e. infeasible
+            } else {
+                const float t = num / den;
+                if (den >= 0.0f) ltr = t;
+                else ltl = t;
+            }
         }
+    } else {
+        if (take0) orca_clip_by(ln, m0, ltl, ltr);
+        if (take1) orca_clip_by(ln, m1, ltl, ltr);  // lines GW .. 2 GW - 1 (more than GW + 1 neighbours only)
     }
     tl = fmaxf(tl, grp_max<GW>(ltl));
     tr = fminf(tr, grp_min<GW>(ltr));
@@ -338,15 +354,38 @@ __device__ __forceinline__ bool orca_lp1_group(const float4 ln, const float4 min
     return true;
 }
 
-// Agent::computeNewVelocity after the half-planes exist: linearProgram2 on the nn sorted lines of agent column `a`
-// with optimisation velocity (ox, oy), then linearProgram3 from the failing line when infeasible (P: private
-// scratch of >= nn - 1 projected lines).
+// projection of half-plane lj onto the boundary of li (linearProgram3); returns false for "parallel, same direction"
+__device__ __forceinline__ bool orca_project(const float4 li, const float4 lj, float4& pj) {
+    const float d = detf(li.z, li.w, lj.z, lj.w);
+    bool have = true;
+    if (fabsf(d) <= RVO_EPS) {
+        if (li.z * lj.z + li.w * lj.w > 0.0f) have = false;
+        pj.x = 0.5f * (li.x + lj.x);
+        pj.y = 0.5f * (li.y + lj.y);
+    } else {
+        const float s = detf(lj.z, lj.w, li.x - lj.x, li.y - lj.y) / d;
+        pj.x = li.x + s * li.z;
+        pj.y = li.y + s * li.w;
+    }
+    const float ddx = lj.z - li.z, ddy = lj.w - li.w;
+    const float inv = 1.0f / sqrtf(ddx * ddx + ddy * ddy);
+    pj.z = ddx * inv;
+    pj.w = ddy * inv;
+    return have;
+}
+
+// Agent::computeNewVelocity after the half-planes exist: linearProgram2 on the sorted lines of agent column `a` with
+// optimisation velocity (ox, oy), then linearProgram3 from the failing line when infeasible.  Lane j of the group holds
+// half-planes j and j + GW.  TWO = false serves nn <= GW + 1 lines: line i only ever meets lines j < i, so half-plane GW
+// (lane 0's second line) is only ever TESTED, never clipped against or projected.  TWO = true serves nn <= 2 GW lines
+// (maxNeighbors follows Config.MAX_NUM_AGENTS_IN_ENVIRONMENT, RVOPolicy.py:15: 19 lines with 20 agents).  P: private
+// scratch of 2 GW projected lines.
 #ifdef CAGYM_STAMPS
 #define LPCOUNT(x) ((x)++)
 #else
 #define LPCOUNT(x) do { } while (0)
 #endif
-template <int GW>
+template <int GW, bool TWO>
 __device__ inline void orca_lp_group(const float4* L, float4* P, int a, int j, int nn, float radius, float ox, float oy,
                                      float& rx, float& ry, int stride, int* lp3_flag = nullptr, int* dbg = nullptr) {
 #ifdef CAGYM_STAMPS
@@ -354,10 +393,9 @@ __device__ inline void orca_lp_group(const float4* L, float4* P, int a, int j, i
 #endif
     const int gbase = (threadIdx.x & 63) & ~(GW - 1);
     const uint64_t gbits = (1ull << GW) - 1ull;
-    const float4 lj = j < nn ? L[j * stride + a] : make_float4(0.f, 0.f, 0.f, 0.f);
-    // nn <= GW + 1: half-plane GW (if any) has no lane of its own; lane 0 also watches it
-    const bool extra = j == 0 && GW < nn;
-    const float4 lx = extra ? L[GW * stride + a] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 l0 = j < nn ? L[j * stride + a] : zero4;
+    const float4 l1 = j + GW < nn ? L[(j + GW) * stride + a] : zero4;
     if (ox * ox + oy * oy > radius * radius) {
         const float inv = 1.0f / sqrtf(ox * ox + oy * oy);
         rx = ox * inv * radius;
@@ -368,18 +406,18 @@ __device__ inline void orca_lp_group(const float4* L, float4* P, int a, int j, i
     }
     // linearProgram2.  The reference walks the lines in order and projects onto each violated one; between two
     // projections the result does not change, so "the next violated line at or after cur" is one parallel test
-    // (lane j tests half-plane j) + a find-first-set.  The groups of a wave then run linearProgram1 in lockstep,
+    // (lane j tests its half-planes) + a find-first-set.  The groups of a wave then run linearProgram1 in lockstep,
     // each on its own line index, instead of diverging over an unrolled loop on i.
     int fail = nn;
     for (int cur = 0; cur < nn;) {  // cur grows by at least 1 per trip: every lane leaves after <= nn trips
-        const bool v1 = j >= cur && j < nn && detf(lj.z, lj.w, lj.x - rx, lj.y - ry) > 0.0f;
-        const bool v2 = extra && GW >= cur && detf(lx.z, lx.w, lx.x - rx, lx.y - ry) > 0.0f;
-        const uint32_t m = (uint32_t)((__ballot(v1) >> gbase) & gbits) | ((uint32_t)((__ballot(v2) >> gbase) & 1ull) << GW);
+        const bool v0 = j >= cur && j < nn && detf(l0.z, l0.w, l0.x - rx, l0.y - ry) > 0.0f;
+        const bool v1 = j + GW >= cur && j + GW < nn && detf(l1.z, l1.w, l1.x - rx, l1.y - ry) > 0.0f;
+        const uint32_t m = (uint32_t)((__ballot(v0) >> gbase) & gbits) | ((uint32_t)((__ballot(v1) >> gbase) & gbits) << GW);
         if (!m) break;
         const int i = __ffs((int)m) - 1;
         LPCOUNT(c_lp2);
         const float4 li = L[i * stride + a];
-        if (!orca_lp1_group<GW>(li, lj, j < i, radius, ox, oy, false, gbase, rx, ry)) {
+        if (!orca_lp1_group<GW, TWO>(li, l0, j < i, l1, j + GW < i, radius, ox, oy, false, rx, ry)) {
             fail = i;  // result keeps the value it had before this line (tempResult)
             break;
         }
@@ -390,48 +428,40 @@ __device__ inline void orca_lp_group(const float4* L, float4* P, int a, int j, i
     float distance = 0.0f;
     if (lp3_flag && fail < nn && j == 0) *lp3_flag = 1;  // this workgroup is in a crowd: its step is the long one
     for (int cur = fail; cur < nn;) {
-        const bool w1 = j >= cur && j < nn && detf(lj.z, lj.w, lj.x - rx, lj.y - ry) > distance;
-        const bool w2 = extra && GW >= cur && detf(lx.z, lx.w, lx.x - rx, lx.y - ry) > distance;
-        const uint32_t wm = (uint32_t)((__ballot(w1) >> gbase) & gbits) | ((uint32_t)((__ballot(w2) >> gbase) & 1ull) << GW);
+        const bool w0 = j >= cur && j < nn && detf(l0.z, l0.w, l0.x - rx, l0.y - ry) > distance;
+        const bool w1 = j + GW >= cur && j + GW < nn && detf(l1.z, l1.w, l1.x - rx, l1.y - ry) > distance;
+        const uint32_t wm = (uint32_t)((__ballot(w0) >> gbase) & gbits) | ((uint32_t)((__ballot(w1) >> gbase) & gbits) << GW);
         if (!wm) break;
         const int i = __ffs((int)wm) - 1;
         cur = i + 1;
         LPCOUNT(c_lp3o);
         const float4 li = L[i * stride + a];
-        // projected line of lane j (j < i); `have` = it exists (not "parallel, same direction")
-        bool have = false;
-        float4 pj = make_float4(0.f, 0.f, 0.f, 0.f);
+        // projected lines of lane j (those of its half-planes that come before i); `have` = it exists
+        bool have0 = false, have1 = false;
+        float4 p0 = zero4, p1 = zero4;
         if (j < i) {
-            const float d = detf(li.z, li.w, lj.z, lj.w);
-            have = true;
-            if (fabsf(d) <= RVO_EPS) {
-                if (li.z * lj.z + li.w * lj.w > 0.0f) have = false;
-                pj.x = 0.5f * (li.x + lj.x);
-                pj.y = 0.5f * (li.y + lj.y);
-            } else {
-                const float s = detf(lj.z, lj.w, li.x - lj.x, li.y - lj.y) / d;
-                pj.x = li.x + s * li.z;
-                pj.y = li.y + s * li.w;
-            }
-            const float ddx = lj.z - li.z, ddy = lj.w - li.w;
-            const float inv = 1.0f / sqrtf(ddx * ddx + ddy * ddy);
-            pj.z = ddx * inv;
-            pj.w = ddy * inv;
-            if (have) P[j] = pj;
+            have0 = orca_project(li, l0, p0);
+            if (have0) P[j] = p0;
+        }
+        if (TWO && j + GW < i) {
+            have1 = orca_project(li, l1, p1);
+            if (have1) P[j + GW] = p1;
         }
         const float px = -li.w, py = li.z;
         const float tx = rx, ty = ry;
         float qx = px * radius, qy = py * radius;  // linearProgram2, directionOpt
         bool failed = false;
         for (int kcur = 0; kcur < i;) {
-            const bool u = have && j >= kcur && detf(pj.z, pj.w, pj.x - qx, pj.y - qy) > 0.0f;
-            const uint32_t um = (uint32_t)((__ballot(u) >> gbase) & gbits);
+            const bool u0 = have0 && j >= kcur && detf(p0.z, p0.w, p0.x - qx, p0.y - qy) > 0.0f;
+            const bool u1 = TWO && have1 && j + GW >= kcur && detf(p1.z, p1.w, p1.x - qx, p1.y - qy) > 0.0f;
+            uint32_t um = (uint32_t)((__ballot(u0) >> gbase) & gbits);
+            if (TWO) um |= (uint32_t)((__ballot(u1) >> gbase) & gbits) << GW;
             if (!um) break;
             const int k = __ffs((int)um) - 1;
             kcur = k + 1;
             LPCOUNT(c_lp3i);
-            const float4 pk = P[k];  // lane k's projected line (same wave: the LDS write above is ordered before this read)
-            if (!orca_lp1_group<GW>(pk, pj, j < k && have, radius, px, py, true, gbase, qx, qy)) {
+            const float4 pk = P[k];  // projected line k (same wave: the LDS write above is ordered before this read)
+            if (!orca_lp1_group<GW, TWO>(pk, p0, j < k && have0, p1, j + GW < k && have1, radius, px, py, true, qx, qy)) {
                 failed = true;
                 break;
             }

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define CAGYM_VERSION 100 /* 0.1.0 */
+#define CAGYM_VERSION 110 /* 0.1.1: cagym_config.rvo_max_neighbors, cagym_kernel_name */
 
 enum { CAGYM_OK = 0, CAGYM_E_INVALID = -1, CAGYM_E_NODEVICE = -2, CAGYM_E_HIP = -3, CAGYM_E_NOMEM = -4,
        CAGYM_E_STATE = -5, CAGYM_E_UNSUPPORTED = -6 };
@@ -66,6 +66,8 @@ typedef struct {
     int32_t laserscan;           /* 1: every agent carries a LaserScanSensor (sensors/LaserScanSensor.py)   */
     int32_t device;              /* HIP device ordinal                                                      */
     double dt;                   /* Config.DT (config.py:29)                                                */
+    int32_t rvo_max_neighbors;   /* RVO maxNeighbors; 0 = max_agents, as policies/RVOPolicy.py:15,25 passes it */
+    int32_t reserved;            /* 0 */
 } cagym_config;
 
 #define CAGYM_EGO_WIDTH 12

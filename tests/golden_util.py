@@ -76,6 +76,29 @@ def canon_oas(oas, n_obs, tie=1e-9):
     return out, ties
 
 
+def oas_mismatch(a, b, n_obs, tol=1e-5, key_tie=1e-5):
+    """Largest abs difference between two worlds' OAS tables [M, K, 10] after matching every row of `a` to the row of `b`
+    that describes the same other agent (nearest (dx, dy)).  Rows may only sit at different positions where their
+    sort keys (column 8) tie within `key_tie`: the order among such rows is decided by last-ulp rounding.  Returns
+    (max abs difference, number of displaced rows); raises AssertionError on an unexplained displacement."""
+    worst, moved = 0.0, 0
+    for i in range(a.shape[0]):
+        n = int(n_obs[i])
+        if n == 0:
+            worst = max(worst, float(np.abs(a[i] - b[i]).max()))
+            continue
+        A, B = np.asarray(a[i, :n], dtype=np.float64), np.asarray(b[i, :n], dtype=np.float64)
+        d = np.abs(A[:, None, 0] - B[None, :, 0]) + np.abs(A[:, None, 1] - B[None, :, 1])
+        p = d.argmin(axis=1)
+        assert len(set(p.tolist())) == n, "rows do not describe the same set of agents"
+        worst = max(worst, float(np.abs(A - B[p]).max()), float(np.abs(a[i, n:] - b[i, n:]).max()) if n < a.shape[1] else 0.0)
+        for r in range(n):
+            if p[r] != r:
+                moved += 1
+                assert abs(B[p[r], 8] - B[r, 8]) <= key_tie, "row %d of agent %d displaced without a key tie" % (r, i)
+    return worst, moved
+
+
 def replay(case, make_env, ftol=1e-12, oas_tol=1e-12, laser_tol=1e-12, check=None, float_keys=None,
            tie=1e-9, reward_tol=None):
     """Step a 1-world backend through the case; returns dict of max abs errors.

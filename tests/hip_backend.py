@@ -11,11 +11,11 @@ HIP_FLOAT_KEYS = ["pos", "vel", "heading", "speed", "delta_heading", "dist_to_go
 
 class HipBackend(object):
     def __init__(self, N, M, max_obstacles=0, game_over_mode=0, laserscan=False, collide_with_static=False,
-                 n_scenarios=None):
+                 n_scenarios=None, rvo_max_neighbors=0):
         from importlib import import_module
         B = import_module("gym-exploration-2d_amd.batched_env").BatchedCollisionAvoidanceEnv
         self.env = B(N, M, n_scenarios=n_scenarios or N, max_obstacles=max_obstacles, game_over_mode=game_over_mode,
-                     collide_with_static=collide_with_static, laserscan=laserscan)
+                     collide_with_static=collide_with_static, laserscan=laserscan, rvo_max_neighbors=rvo_max_neighbors)
         self.N, self.M = N, M
 
     def set_scenario(self, agents6, policy_id, dynamics_id, heading0=None, n_agents=None, coop=None,

