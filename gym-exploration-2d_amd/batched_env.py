@@ -176,13 +176,15 @@ class BatchedCollisionAvoidanceEnv(object):
         if obs:
             buf["other_agents_states"] = torch.empty((T, N, M, K, 10), dtype=torch.float32, device=dev)
             buf["ego"] = torch.empty((T, N, M, _lib.EGO_WIDTH), dtype=torch.float32, device=dev)
+            if self.laserscan:
+                buf["laserscan"] = torch.empty((T, N, M, 16), dtype=torch.float32, device=dev)
         return buf
 
     def rollout(self, n_steps, auto_reset=True, out=None):
         """n_steps env steps in one launch (all agents internally driven); returns [T, ...] buffers."""
         if out is None:
             out = self.alloc_rollout(n_steps)
-        o = self._outputs(out.get("other_agents_states"), out.get("ego"), None, out.get("reward"),
+        o = self._outputs(out.get("other_agents_states"), out.get("ego"), out.get("laserscan"), out.get("reward"),
                           out.get("flags"), out.get("game_over"))
         with torch.cuda.device(self.device):
             rc = self.L.cagym_rollout(self.h, int(n_steps), int(bool(auto_reset)), C.byref(o), self._stream())

@@ -31,6 +31,7 @@ struct Env {
     uint32_t* ig_any = nullptr;
     bool ig_ready = false;
     int any_rvo = 1;
+    int obst_rvo = 0;    // RVO agents in worlds with rectangles: the kernels build obstacle half-planes (OBST instantiations)
     int generation = 3;  // CAGYM_KERNEL=v1 selects the one-lane-per-agent kernels (bitwise A/B only)
     int wpw10 = 5;       // worlds per workgroup of the M = 10 kernels (4 while all workgroups are co-resident)
 };
@@ -126,9 +127,15 @@ inline int n_wg2(const Env* e) {
     const int wpw = wpw_spec(e) ? wpw_spec(e) : CAGYM_WAVE / M;
     return (e->cfg.n_worlds + wpw - 1) / wpw;
 }
-inline size_t lds3_bytes(const Env* e) {
+inline size_t lds3_bytes(const Env* e, bool obst) {
     const int M = e->cfg.max_agents;
-    return cagym_lds3_bytes(M, cagym_as(M, wpw_spec(e)), spec2(e).nt);
+    return cagym_lds3_bytes(M, cagym_as(M, wpw_spec(e)), spec2(e).nt, obst ? 2 * e->cfg.max_obstacles : 0, obst ? 4 : 2);
+}
+inline size_t lds3_bytes(const Env* e) { return lds3_bytes(e, e->obst_rvo != 0); }
+// LP group width of the handle's specialisation (run_steps3)
+inline int lp_group_width(const Env* e) {
+    const int mt = spec2(e).mt;
+    return mt > 0 && mt <= 5 ? 4 : (mt > 0 && mt <= 10 ? CAGYM_GW10 : 16);
 }
 
 inline int n_waves(const Env* e) {
@@ -137,11 +144,17 @@ inline int n_waves(const Env* e) {
 }
 
 template <int NT, int MT, int WP>
-void set_lds_attr3(int lds3) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_step3<NT, MT, WP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds3);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_step3<NT, MT, WP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds3);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout3<NT, MT, WP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds3);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout3<NT, MT, WP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds3);
+void set_lds_attr3(int lds3, int lds3_obst) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_step3<NT, MT, WP, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds3);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_step3<NT, MT, WP, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds3);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout3<NT, MT, WP, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds3);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout3<NT, MT, WP, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds3);
+    if (lds3_obst <= 160 * 1024) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_step3<NT, MT, WP, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds3_obst);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_step3<NT, MT, WP, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds3_obst);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout3<NT, MT, WP, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds3_obst);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout3<NT, MT, WP, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds3_obst);
+    }
 }
 
 // the one place that maps a handle to its kernel instantiation
@@ -207,7 +220,7 @@ int cagym_create(const cagym_config* cfg, void** env_out) {
         A(dalloc(e, &e->sc_obst, S * (size_t)cfg->max_obstacles * 4));
     }
     D.sc_agents6 = d6; D.sc_heading0 = nullptr; D.sc_coop = dcoop; D.sc_policy = dpol; D.sc_dyn = ddyn;
-    D.sc_nagents = dna; D.sc_nobst = dno; D.map_bits = dmap;
+    D.sc_nagents = dna; D.sc_nobst = dno; D.map_bits = dmap; D.sc_obst = e->sc_obst;
     A(dalloc(e, &D.px, NM)); A(dalloc(e, &D.py, NM)); A(dalloc(e, &D.vx, NM)); A(dalloc(e, &D.vy, NM));
     A(dalloc(e, &D.heading, NM)); A(dalloc(e, &D.heading_ego, NM)); A(dalloc(e, &D.dist_goal, NM));
     A(dalloc(e, &D.time_rem, NM)); A(dalloc(e, &D.t, NM)); A(dalloc(e, &D.gx, NM)); A(dalloc(e, &D.gy, NM));
@@ -239,9 +252,9 @@ int cagym_create(const cagym_config* cfg, void** env_out) {
             const char* w = getenv("CAGYM_WPW10");  // diagnostics
             if (w && (w[0] == '4' || w[0] == '5')) e->wpw10 = w[0] - '0';
         }
-        int lds3 = (int)lds3_bytes(e);
+        int lds3 = (int)lds3_bytes(e, false), lds3_obst = (int)lds3_bytes(e, true);
         if (e->generation == 3 && lds3 > 160 * 1024) e->generation = 1;
-#define SETATTR(NT, MT, WP) set_lds_attr3<NT, MT, WP>(lds3)
+#define SETATTR(NT, MT, WP) set_lds_attr3<NT, MT, WP>(lds3, lds3_obst)
         CAGYM_DISPATCH2(e, SETATTR);
 #undef SETATTR
     }
@@ -283,6 +296,28 @@ int cagym_set_scenarios(void* env, const double* agents6, const double* heading0
         if (n_obst && e->cfg.max_obstacles > 0) {
             no[s] = n_obst[s];
             if (no[s] < 0 || no[s] > e->cfg.max_obstacles) return fail(e, CAGYM_E_INVALID, "n_obst out of range");
+        }
+    }
+    // RVO agents among rectangles: the kernels build obstacle half-planes (RVOPolicy.py:56-57).  Capacity of an LP group:
+    // 4 half-planes per lane; an agent sees at most 2 edges of a rectangle from their right side.
+    {
+        bool any_obst = false;
+        for (size_t sc = 0; sc < S; sc++) any_obst |= no[sc] > 0;
+        e->obst_rvo = (any_obst && e->any_rvo) ? 1 : 0;
+        if (e->obst_rvo) {
+            const int K = e->cfg.max_obstacles, gw = lp_group_width(e);
+            const Spec2 sp = spec2(e);
+            const int as = cagym_as((int)M, sp.wpw);
+            if (e->generation != 3) return fail(e, CAGYM_E_UNSUPPORTED, "RVO agents among obstacles need the generation-3 kernels");
+            if (2 * K + (int)M - 1 > 4 * gw || (size_t)2 * K * as * 8 > (size_t)4 * sp.nt * 16 || lds3_bytes(e, true) > 160 * 1024)
+                return fail(e, CAGYM_E_UNSUPPORTED, "too many rectangles per world for RVO agents at this max_agents (2 * max_obstacles + max_agents - 1 half-planes per ego)");
+            if (obstacles)
+                for (size_t sc = 0; sc < S; sc++)
+                    for (int k = 0; k < no[sc]; k++) {
+                        const double* r = obstacles + (sc * K + k) * 4;
+                        if (!(r[2] > r[0]) || !(r[3] > r[1]))
+                            return fail(e, CAGYM_E_INVALID, "RVO agents need non-degenerate rectangles (xl < xu, yl < yu)");
+                    }
         }
     }
     std::vector<double> cp(SM, 1.0);  // agent.py:10
@@ -347,6 +382,7 @@ int cagym_generate_scenarios(void* env, const cagym_gen_params* params, int32_t*
     HIPCHK(e, hipGetLastError());
     D.sc_heading0 = nullptr;  // toward the goal (agent.py:29-31)
     e->any_rvo = (P.ego_policy == CAGYM_POL_RVO || P.policy_a == CAGYM_POL_RVO || P.policy_b == CAGYM_POL_RVO) ? 1 : 0;
+    e->obst_rvo = 0;  // the generator draws free-space worlds
     if (e->cfg.max_obstacles > 0) {  // free space: empty rasters
         hipLaunchKernelGGL(k_rasterize, dim3((unsigned)G.S), dim3(256), 0, st, e->sc_obst, D.sc_nobst, e->cfg.max_obstacles,
                            const_cast<uint32_t*>(D.map_bits));
@@ -394,15 +430,20 @@ int cagym_step(void* env, const float* ext_actions, const cagym_outputs* out, vo
     DEVGUARD(e);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     CagymOut o = to_out(out);
+    if (!e->cfg.laserscan) o.laserscan = nullptr;
     if (e->generation == 3) {
         const size_t lds3 = lds3_bytes(e);
-#define STEP3(NT, MT, WP) hipLaunchKernelGGL((k_step3<NT, MT, WP, false>), dim3(n_wg2(e)), dim3(NT), lds3, st, e->D, ext_actions, o, e->any_rvo)
+#define STEP3(NT, MT, WP)                                                                                                        \
+    do {                                                                                                                     \
+        if (e->obst_rvo) hipLaunchKernelGGL((k_step3<NT, MT, WP, false, true>), dim3(n_wg2(e)), dim3(NT), lds3, st, e->D, ext_actions, o, e->any_rvo); \
+        else hipLaunchKernelGGL((k_step3<NT, MT, WP, false, false>), dim3(n_wg2(e)), dim3(NT), lds3, st, e->D, ext_actions, o, e->any_rvo);       \
+    } while (0)
         CAGYM_DISPATCH2(e, STEP3);
 #undef STEP3
     } else
     hipLaunchKernelGGL(k_step, dim3(n_waves(e)), dim3(64), cagym_lds_bytes(e->cfg.max_agents), st, e->D, ext_actions, o);
     HIPCHK(e, hipGetLastError());
-    if (e->cfg.laserscan && o.laserscan) return cagym_laserscan(env, o.laserscan, stream);
+    if (e->generation != 3 && e->cfg.laserscan && o.laserscan) return cagym_laserscan(env, o.laserscan, stream);  // generation 3 scans in-kernel
     return CAGYM_OK;
 }
 
@@ -413,16 +454,20 @@ int cagym_step_autoreset(void* env, const float* ext_actions, const cagym_output
     DEVGUARD(e);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     CagymOut o = to_out(out);
+    if (!e->cfg.laserscan) o.laserscan = nullptr;
     if (e->generation == 3) {
         const size_t lds3 = lds3_bytes(e);
-#define STEP3(NT, MT, WP) hipLaunchKernelGGL((k_step3<NT, MT, WP, true>), dim3(n_wg2(e)), dim3(NT), lds3, st, e->D, ext_actions, o, e->any_rvo)
+#define STEP3(NT, MT, WP)                                                                                                        \
+    do {                                                                                                                     \
+        if (e->obst_rvo) hipLaunchKernelGGL((k_step3<NT, MT, WP, true, true>), dim3(n_wg2(e)), dim3(NT), lds3, st, e->D, ext_actions, o, e->any_rvo); \
+        else hipLaunchKernelGGL((k_step3<NT, MT, WP, true, false>), dim3(n_wg2(e)), dim3(NT), lds3, st, e->D, ext_actions, o, e->any_rvo);       \
+    } while (0)
         CAGYM_DISPATCH2(e, STEP3);
 #undef STEP3
     } else
         return fail(e, CAGYM_E_UNSUPPORTED, "cagym_step_autoreset needs the generation-3 kernels");
     HIPCHK(e, hipGetLastError());
-    if (e->cfg.laserscan && o.laserscan) return cagym_laserscan(env, o.laserscan, stream);
-    return CAGYM_OK;
+    return CAGYM_OK;  // the scan of the (possibly restarted) worlds is part of the launch
 }
 
 int cagym_rollout(void* env, int n_steps, int auto_reset, const cagym_outputs* out, void* stream) {
@@ -431,18 +476,21 @@ int cagym_rollout(void* env, int n_steps, int auto_reset, const cagym_outputs* o
     if (!e->scenarios_set) return fail(e, CAGYM_E_STATE, "cagym_rollout before cagym_set_scenarios");
     DEVGUARD(e);
     if (n_steps < 1) return fail(e, CAGYM_E_INVALID, "n_steps must be >= 1");
-    if (e->cfg.laserscan && out && out->laserscan)
-        return fail(e, CAGYM_E_UNSUPPORTED, "cagym_rollout does not produce laserscan (use cagym_step)");
+    if (e->cfg.laserscan && out && out->laserscan && e->generation != 3)
+        return fail(e, CAGYM_E_UNSUPPORTED, "cagym_rollout produces laserscan with the generation-3 kernels only");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     CagymOut o = to_out(out);
+    if (!e->cfg.laserscan) o.laserscan = nullptr;
     size_t lds = cagym_lds_bytes(e->cfg.max_agents);
     if (e->generation == 3) {
         const size_t lds3 = lds3_bytes(e);
         const dim3 g(n_wg2(e));
 #define ROLL3(NT, MT, WP)                                                                                              \
     do {                                                                                                           \
-        if (auto_reset) hipLaunchKernelGGL((k_rollout3<NT, MT, WP, true>), g, dim3(NT), lds3, st, e->D, n_steps, o, e->any_rvo); \
-        else hipLaunchKernelGGL((k_rollout3<NT, MT, WP, false>), g, dim3(NT), lds3, st, e->D, n_steps, o, e->any_rvo);         \
+        if (auto_reset && e->obst_rvo) hipLaunchKernelGGL((k_rollout3<NT, MT, WP, true, true>), g, dim3(NT), lds3, st, e->D, n_steps, o, e->any_rvo); \
+        else if (auto_reset) hipLaunchKernelGGL((k_rollout3<NT, MT, WP, true, false>), g, dim3(NT), lds3, st, e->D, n_steps, o, e->any_rvo); \
+        else if (e->obst_rvo) hipLaunchKernelGGL((k_rollout3<NT, MT, WP, false, true>), g, dim3(NT), lds3, st, e->D, n_steps, o, e->any_rvo); \
+        else hipLaunchKernelGGL((k_rollout3<NT, MT, WP, false, false>), g, dim3(NT), lds3, st, e->D, n_steps, o, e->any_rvo);         \
     } while (0)
         CAGYM_DISPATCH2(e, ROLL3);
 #undef ROLL3

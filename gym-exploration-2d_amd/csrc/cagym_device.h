@@ -35,6 +35,7 @@ struct CagymDev {
     const double* sc_coop;
     const int32_t* sc_nobst;
     const uint32_t* map_bits;  // [S,300,10] or null
+    const double* sc_obst;     // [S,Kobs,4] xl, yl, xu, yu or null
     // state [N*M]
     double *px, *py, *vx, *vy, *heading, *heading_ego, *dist_goal, *time_rem, *t;
     double *gx, *gy, *radius, *pref, *speed, *dhead, *aux0, *aux1, *coop;

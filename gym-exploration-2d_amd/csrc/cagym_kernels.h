@@ -424,21 +424,13 @@ __global__ void __launch_bounds__(64) k_reset(CagymDev D, const uint8_t* mask, i
     sense_and_store(D, W, C, A, out, wr, false);
 }
 
-// LaserScanSensor.sense (sensors/LaserScanSensor.py:9-22,27-58): one lane per (agent, beam).
-__global__ void __launch_bounds__(256) k_laserscan(CagymDev D, float* out) {
-    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t total = (size_t)D.N * D.M * 16;
-    if (gid >= total) return;
-    const size_t a = gid >> 4;
-    const int b = (int)(gid & 15);
-    const int world = (int)(a / D.M), slot = (int)(a - (size_t)world * D.M);
-    if (slot >= D.n_agents[world]) { out[gid] = 0.f; return; }
-    const int sidx = (int)(((long long)world + (long long)D.episode[world] * D.N) % D.S);
-    const uint32_t* map = (D.map_bits && D.sc_nobst[sidx] > 0) ? D.map_bits + (size_t)sidx * CAGYM_MAPD * CAGYM_MAPW : nullptr;
-    const double px = D.px[a], py = D.py[a], h = D.heading[a];
+// LaserScanSensor.sense (sensors/LaserScanSensor.py:9-22,27-58), beam b of an agent at (px, py, heading h) with
+// `radius`: 16 samples at 2 pi / 16 m into the bit-packed raster `map` (null = empty map), the agent's own disk masked,
+// the LAST sample whose running hit count is 1 gives the range.
+__device__ __forceinline__ float laserscan_beam(const uint32_t* map, double px, double py, double h, double radius, int b) {
     int egx, egy;
     const bool ego_in = world_to_cell(px, py, egx, egy);
-    const double rr = D.radius[a] / 0.1, r2 = rr * rr;
+    const double rr = radius / 0.1, r2 = rr * rr;
     const double astep = (kPi - (-kPi)) / 15.0, rstep = 2 * kPi / 16;
     const double ang0 = b == 15 ? kPi : (double)b * astep + (-kPi);
     double sa, ca;
@@ -461,7 +453,21 @@ __global__ void __launch_bounds__(256) k_laserscan(CagymDev D, float* out) {
         if (count == 1) last = k;
     }
     double range = last >= 0 ? 0.0 + (double)last * rstep : 6.0;
-    out[gid] = (float)(1 - range / 6);
+    return (float)(1 - range / 6);
+}
+
+// one lane per (agent, beam) of the state in HBM (cagym_laserscan, cagym_reset)
+__global__ void __launch_bounds__(256) k_laserscan(CagymDev D, float* out) {
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)D.N * D.M * 16;
+    if (gid >= total) return;
+    const size_t a = gid >> 4;
+    const int b = (int)(gid & 15);
+    const int world = (int)(a / D.M), slot = (int)(a - (size_t)world * D.M);
+    if (slot >= D.n_agents[world]) { out[gid] = 0.f; return; }
+    const int sidx = (int)(((long long)world + (long long)D.episode[world] * D.N) % D.S);
+    const uint32_t* map = (D.map_bits && D.sc_nobst[sidx] > 0) ? D.map_bits + (size_t)sidx * CAGYM_MAPD * CAGYM_MAPW : nullptr;
+    out[gid] = laserscan_beam(map, D.px[a], D.py[a], D.heading[a], D.radius[a], b);
 }
 
 // OccupancyGridSensor.sense (sensors/OccupancyGridSensor.py:70-98, 131-143; Map.getSubmapByIndices Map.py:81-105):

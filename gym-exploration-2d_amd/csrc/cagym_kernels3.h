@@ -141,30 +141,36 @@ struct Lds3 {
     int* tstep;
     int* tmoved;   // [AS] the agent moved in this step's S1 (ego frame still to be updated)
     int* trvo;     // [AS] live RVO ego as of the last S1 (the next step's half-planes are built beside S2)
+    int* nobl;     // [AS] obstacle half-planes of the ego (rows 0 .. nobl-1 of its column of `sorted`)
     int* wn;       // [32] agents per world of this workgroup
+    int* wsc;      // [32] scenario of the world's current episode (rectangles, raster)
     int* flag;     // [8]  0: a world was reset this step   1: OAS row chunks claimed   2: LP waves finished
+                   //      3/4: some ego needed linearProgram3 this / the previous step
     float2* lpv;   // [AS] preferred (optimisation) velocity of each ego
     float2* lpc;   // [AS] pref velocity clipped to maxSpeed = LP start; LP result afterwards
     float* lpr;    // [AS] maxSpeed of the ego (LP radius)
     int* lpk;      // [AS] compact list of the busy egos
     int* busy;     // [AS] some half-plane of the ego is violated by its LP start
     float* dsq;      // [AS*MP]       squared centre distance ego->slot, fp32 as RVO2 (+inf = no such neighbour)
-    float4* sorted;  // [M - 1][AS]   half-planes nearest-first (maxNeighbors <= M - 1 of them are used)
-    float4* lp3;     // [2 NT]        linearProgram3 scratch, 2 GW entries per LP group
+    float4* sorted;  // [ko + M - 1][AS]  half-planes in solve order: rows < ko obstacle lines (ko = 2 rectangles' worth per
+                     //                  rectangle, 0 without obstacles), rows ko + rank agent lines nearest-first
+    float4* lp3;     // [lpl NT]      linearProgram3 scratch, lpl GW entries per LP group (lpl = 2, 4 with obstacles); the
+                     //               obstacle-neighbour sort of phase A borrows it
     double* keys;    // [AS*MP]       OAS sort key (-inf = not observed)
     double* gap;     // [AS*MP]       d - (r_i + r_j) for the lower index of a pair, else +inf
     uint8_t* hit;    // [AS*MP]       pair collides
 };
 
 __host__ __device__ inline size_t cagym_lds3_head(int AS) {
-    return (size_t)20 * AS * 8 + AS * 8 + (size_t)5 * AS * 4 + 32 * 4 + 8 * 4 + (size_t)2 * AS * 8 + (size_t)3 * AS * 4;
+    return (size_t)20 * AS * 8 + AS * 8 + (size_t)6 * AS * 4 + 64 * 4 + 8 * 4 + (size_t)2 * AS * 8 + (size_t)3 * AS * 4;
 }
-__host__ __device__ inline size_t cagym_lds3_bytes(int M, int AS, int NT) {
+// ko: rows of `sorted` reserved for obstacle lines; lpl: half-planes per lane of an LP group
+__host__ __device__ inline size_t cagym_lds3_bytes(int M, int AS, int NT, int ko = 0, int lpl = 2) {
     const size_t MP = cagym_mp(M);
-    return a16(cagym_lds3_head(AS)) + a16(AS * MP * 4) + (size_t)(M - 1) * AS * 16 + (size_t)2 * NT * 16 + 2 * AS * MP * 8 + a16(AS * MP);
+    return a16(cagym_lds3_head(AS)) + a16(AS * MP * 4) + (size_t)(ko + M - 1) * AS * 16 + (size_t)lpl * NT * 16 + 2 * AS * MP * 8 + a16(AS * MP);
 }
 
-__device__ __forceinline__ Lds3 carve_lds3(unsigned char* smem, int M, int AS, int NT) {
+__device__ __forceinline__ Lds3 carve_lds3(unsigned char* smem, int M, int AS, int NT, int ko = 0, int lpl = 2) {
     Lds3 W;
     const size_t MP = cagym_mp(M);
     W.tpx = reinterpret_cast<double*>(smem);
@@ -183,15 +189,17 @@ __device__ __forceinline__ Lds3 carve_lds3(unsigned char* smem, int M, int AS, i
     W.lpr = reinterpret_cast<float*>(W.trvo + AS);
     W.lpk = reinterpret_cast<int*>(W.lpr + AS);
     W.busy = W.lpk + AS;
-    W.wn = W.busy + AS;
-    W.flag = W.wn + 32;
+    W.nobl = W.busy + AS;
+    W.wn = W.nobl + AS;
+    W.wsc = W.wn + 32;
+    W.flag = W.wsc + 32;
     unsigned char* u = smem + a16(cagym_lds3_head(AS));
     W.dsq = reinterpret_cast<float*>(u);
     u += a16(AS * MP * 4);
     W.sorted = reinterpret_cast<float4*>(u);
-    u += (size_t)(M - 1) * AS * 16;
+    u += (size_t)(ko + M - 1) * AS * 16;
     W.lp3 = reinterpret_cast<float4*>(u);
-    u += (size_t)2 * NT * 16;
+    u += (size_t)lpl * NT * 16;
     W.keys = reinterpret_cast<double*>(u);
     W.gap = W.keys + AS * MP;
     W.hit = reinterpret_cast<uint8_t*>(W.gap + AS * MP);
@@ -260,6 +268,36 @@ __device__ __forceinline__ void publish_pref_velocity3(const Lds3& W, int a) {
     }
     W.lpc[a] = make_float2(cx, cy);
     W.busy[a] = 0;
+}
+
+// Everything of the next ORCA solve that depends on ego a alone: preferred velocity / LP start and, in worlds with
+// rectangles, the obstacle half-planes (one lane per ego; RVOPolicy.py:56-57, Agent::computeNewVelocity's first half).
+// The obstacle lines go to rows 0 .. nobl-1 of the ego's column; the busy test covers them like the agent lines.
+template <bool OBST>
+__device__ __forceinline__ void ego_lp_inputs3(const CagymDev& D, const Lds3& W, int a, int M, int AS, int ko, uint32_t inv_m) {
+    publish_pref_velocity3(W, a);
+    if (!OBST) return;
+    int no = 0;
+    if (W.trvo[a]) {
+        const int wl = (int)__umulhi((uint32_t)a, inv_m);
+        const int sidx = W.wsc[wl];
+        const int n_obst = D.sc_nobst[sidx];
+        if (n_obst > 0) {
+            const float px = (float)W.tpx[a], py = (float)W.tpy[a], vx = (float)W.tvx[a], vy = (float)W.tvy[a];
+            const float radius = (float)((1 + 15e-2) * W.tr[a]), max_speed = W.lpr[a];
+            float2* nbr = reinterpret_cast<float2*>(W.lp3) + a;  // private column of the (idle) linearProgram3 scratch
+            no = orca_obstacle_lines(D.sc_obst + (size_t)sidx * D.Kobs * 4, n_obst, px, py, vx, vy, radius, max_speed, 5.0f,
+                                     W.sorted + a, AS, ko, nbr, AS);
+            const float2 s0 = W.lpc[a];
+            bool viol = false;
+            for (int k = 0; k < no; k++) {
+                const float4 ln = W.sorted[k * AS + a];
+                viol |= detf(ln.z, ln.w, ln.x - s0.x, ln.y - s0.y) > 0.0f;
+            }
+            if (viol) W.busy[a] = 1;
+        }
+    }
+    W.nobl[a] = no;
 }
 
 // unordered pair p of the workgroup -> (world of the workgroup, i, j); compile-time M or run-time M (magic division)
@@ -348,7 +386,7 @@ __device__ __forceinline__ int neighbour_rank3(const Lds3& W, int a, int sl, flo
 
 // ---- phase B body: ORCA half-planes of one unordered pair, ranked into both egos' nearest-first line lists -----------------
 template <int MT>
-__device__ __forceinline__ void half_planes3(const CagymDev& D, const Lds3& W, int p, int M, int MP, int AS) {
+__device__ __forceinline__ void half_planes3(const CagymDev& D, const Lds3& W, int p, int M, int MP, int AS, int ko) {
     const UPair q = upair_of<MT>(p, M);
     const int n = W.wn[q.wl];
     const int a = q.wl * M + q.i, b = q.wl * M + q.j;
@@ -365,7 +403,7 @@ __device__ __forceinline__ void half_planes3(const CagymDev& D, const Lds3& W, i
         const float2 s0 = W.lpc[a];
         if (detf(ln.z, ln.w, ln.x - s0.x, ln.y - s0.y) > 0.0f) W.busy[a] = 1;
         const int rank = neighbour_rank3<MT>(W, a, q.j, g.d2, MP);
-        if (rank < D.maxnb) W.sorted[rank * AS + a] = ln;
+        if (rank < D.maxnb) W.sorted[(ko + rank) * AS + a] = ln;
     }
     if (on_b) {
         const float c = W.tcoop[b];
@@ -373,7 +411,7 @@ __device__ __forceinline__ void half_planes3(const CagymDev& D, const Lds3& W, i
         const float2 s0 = W.lpc[b];
         if (detf(ln.z, ln.w, ln.x - s0.x, ln.y - s0.y) > 0.0f) W.busy[b] = 1;
         const int rank = neighbour_rank3<MT>(W, b, q.i, g.d2, MP);
-        if (rank < D.maxnb) W.sorted[rank * AS + b] = ln;
+        if (rank < D.maxnb) W.sorted[(ko + rank) * AS + b] = ln;
     }
 }
 
@@ -445,22 +483,42 @@ __device__ __forceinline__ void ego_obs3(const CagymDev& D, const Lds3& W, float
     }
 }
 
+// LaserScanSensor of agent slot a, beam b (16 beams x 16 samples gathered from the world's bit-packed raster, L2-resident)
+__device__ __forceinline__ void laser_beam3(const CagymDev& D, const Lds3& W, float* laser_out, int a, int b, int M, int wpw,
+                                            uint32_t inv_m) {
+    if (a >= wpw * M) return;
+    const int wl = (int)__umulhi((uint32_t)a, inv_m);
+    const int slot = a - wl * M;
+    const int world = blockIdx.x * wpw + wl;
+    if (world >= D.N) return;
+    float v = 0.f;
+    if (slot < W.wn[wl]) {
+        const int sidx = W.wsc[wl];
+        const uint32_t* map = (D.map_bits && D.sc_nobst[sidx] > 0) ? D.map_bits + (size_t)sidx * CAGYM_MAPD * CAGYM_MAPW : nullptr;
+        v = laserscan_beam(map, W.tpx[a], W.tpy[a], W.th[a], W.tr[a], b);
+    }
+    laser_out[((size_t)world * M + slot) * 16 + b] = v;
+}
+
 // claim-and-process loop of the observation workers: chunks 0 .. nck-1 are 64 directed pairs each, chunk nck is the
-// scalar-observation store of the agent slots.  Every wave of the workgroup may call it; a wave leaves when the
+// scalar-observation store of the agent slots, chunks nck+1 .. are 4 agents x 16 laser beams each (when asked for).  Every wave of the workgroup may call it; a wave leaves when the
 // counter has run past the last chunk (every wave reaches that: the counter only grows).
 __device__ __forceinline__ void observation_chunks3(const CagymDev& D, const Lds3& W, const CagymOut& o, int npairs, int M, int MP,
                                                     int K, int wpw, int worlds_valid, uint32_t inv_m) {
     const int lane = threadIdx.x & (CAGYM_WAVE - 1);
     const int nck = (npairs + CAGYM_WAVE - 1) / CAGYM_WAVE;
+    const int nlaser = o.laserscan ? (wpw * M + 3) / 4 : 0;
     for (;;) {
         int c = 0;
         if (lane == 0) c = __hip_atomic_fetch_add(&W.flag[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         c = __builtin_amdgcn_readfirstlane(c);
-        if (c > nck) break;
+        if (c > nck + nlaser) break;
         if (c < nck) {
             if (o.obs_oas) oas_row3(W, o.obs_oas, c * CAGYM_WAVE + lane, npairs, M, MP, K, wpw, worlds_valid, inv_m);
-        } else {
+        } else if (c == nck) {
             ego_obs3(D, W, o.obs_ego, lane, M, wpw, inv_m);
+        } else {
+            laser_beam3(D, W, o.laserscan, (c - nck - 1) * 4 + (lane >> 4), lane & 15, M, wpw, inv_m);
         }
     }
 }
@@ -469,7 +527,7 @@ __device__ __forceinline__ CagymOut out_slice3(const CagymOut& out, int t, size_
     CagymOut o;
     o.obs_oas = out.obs_oas ? out.obs_oas + (size_t)t * NM * (M - 1) * 10 : nullptr;
     o.obs_ego = out.obs_ego ? out.obs_ego + (size_t)t * NM * CAGYM_EGO_WIDTH : nullptr;
-    o.laserscan = nullptr;
+    o.laserscan = out.laserscan ? out.laserscan + (size_t)t * NM * 16 : nullptr;
     o.reward = out.reward ? out.reward + (size_t)t * NM : nullptr;
     o.flags = out.flags ? out.flags + (size_t)t * NM : nullptr;
     o.game_over = out.game_over ? out.game_over + (size_t)t * N : nullptr;
@@ -477,7 +535,8 @@ __device__ __forceinline__ CagymOut out_slice3(const CagymOut& out, int t, size_
 }
 
 // n_steps env.step() calls of the workgroup's worlds.  ext: external actions of the (single) step or null.
-template <int NT, int MT, int WPWT, bool AUTO_RESET>
+// OBST: the handle has rectangles and RVO agents (obstacle half-planes, LP groups with 4 half-planes per lane).
+template <int NT, int MT, int WPWT, bool AUTO_RESET, bool OBST>
 __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const float* ext, const CagymOut& out, int n_steps,
                                   bool any_rvo) {
     constexpr int NWAVES = NT / CAGYM_WAVE;
@@ -485,7 +544,9 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
     constexpr bool TWO = !(MT > 0 && MT - 1 <= GW + 1);  // more than GW + 1 half-planes possible: two per lane of an LP group
     const int M = MT ? MT : D.M, K = M - 1, MP = cagym_mp(M);
     const int AS = cagym_as(M, WPWT);
-    const Lds3 W = carve_lds3(smem, M, AS, NT);
+    const int ko = OBST ? 2 * D.Kobs : 0;  // an agent outside a rectangle sees at most 2 of its edges from their right side
+    constexpr int LPL = OBST ? 4 : 2;
+    const Lds3 W = carve_lds3(smem, M, AS, NT, ko, LPL);
     LaneCtx C = make_ctx2(D, M, WPWT ? WPWT : CAGYM_WAVE / M);
     const uint32_t inv_m = (uint32_t)(0x100000000ull / (uint32_t)M) + 1u;
     const int nagents = C.wpw * M;               // agent slots of this workgroup (<= 64: wave 0)
@@ -509,8 +570,11 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
             lds3_store_agent(W, A, tid);
             W.tmoved[tid] = 0;
             W.trvo[tid] = live_rvo(A.st, C.valid && C.active);
-            if (C.wl < C.wpw && C.slot == 0) W.wn[C.wl] = C.valid ? C.n : 0;
-            publish_pref_velocity3(W, tid);
+            W.nobl[tid] = 0;
+            if (C.wl < C.wpw && C.slot == 0) {
+                W.wn[C.wl] = C.valid ? C.n : 0;
+                W.wsc[C.wl] = C.valid ? (int)(((long long)C.world + (long long)C.episode * D.N) % D.S) : 0;
+            }
             // constant entries of the distance / key rows: own slot and the padding
             W.dsq[tid * MP + C.slot] = INFINITY;
             W.hit[tid * MP + C.slot] = 0;
@@ -525,10 +589,12 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
         }
         if (tid < 8) W.flag[tid] = 0;
         __syncthreads();
+        if (agent_lane && any_rvo) ego_lp_inputs3<OBST>(D, W, tid, M, AS, ko, inv_m);
+        else if (agent_lane) publish_pref_velocity3(W, tid);
         if (any_rvo) {
             for (int p = tid; p < nup; p += NT) pair_distances3<MT>(D, W, p, M, MP);
             __syncthreads();
-            for (int p = tid; p < nup; p += NT) half_planes3<MT>(D, W, p, M, MP, AS);
+            for (int p = tid; p < nup; p += NT) half_planes3<MT>(D, W, p, M, MP, AS, ko);
         }
         __syncthreads();
     }
@@ -584,11 +650,16 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
                     const float2 pv = W.lpv[a];
                     const float rad = W.lpr[a];
                     float vx, vy;
+                    if (OBST) {
+                        orca_lp_group_n<GW, LPL>(W.sorted, W.lp3 + LPL * (tid & ~(GW - 1)), a, j, W.nobl[a], nn, ko, rad, pv.x, pv.y,
+                                                 vx, vy, AS, &W.flag[3]);
+                    } else {
 #ifdef CAGYM_STAMPS
-                    orca_lp_group<GW, TWO>(W.sorted, W.lp3 + 2 * (tid & ~(GW - 1)), a, j, nn, rad, pv.x, pv.y, vx, vy, AS, &W.flag[3], dbg);
+                        orca_lp_group<GW, TWO>(W.sorted, W.lp3 + 2 * (tid & ~(GW - 1)), a, j, nn, rad, pv.x, pv.y, vx, vy, AS, &W.flag[3], dbg);
 #else
-                    orca_lp_group<GW, TWO>(W.sorted, W.lp3 + 2 * (tid & ~(GW - 1)), a, j, nn, rad, pv.x, pv.y, vx, vy, AS, &W.flag[3]);
+                        orca_lp_group<GW, TWO>(W.sorted, W.lp3 + 2 * (tid & ~(GW - 1)), a, j, nn, rad, pv.x, pv.y, vx, vy, AS, &W.flag[3]);
 #endif
+                    }
                     if (j == 0) W.lpc[a] = make_float2(vx, vy);
                 }
             }
@@ -678,7 +749,7 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
                     update_ego_frame(E, prx, pry);
                     W.tdg[a] = E.dg; W.the[a] = E.he; W.tprx[a] = prx; W.tpry[a] = pry;
                 }
-                if (any_rvo) publish_pref_velocity3(W, a);
+                if (any_rvo) ego_lp_inputs3<OBST>(D, W, a, M, AS, ko, inv_m);
             }
         }
         for (int p = tid; p < nup; p += NT) pair_distances3<MT>(D, W, p, M, MP);
@@ -764,7 +835,7 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
                             C.active = C.slot < C.n;
                             init_agent(D, S, sidx, C.slot, C.active);
                             lds3_store_agent(W, S, tid);
-                            if (C.slot == 0) W.wn[C.wl] = C.n;
+                            if (C.slot == 0) { W.wn[C.wl] = C.n; W.wsc[C.wl] = sidx; }
                         }
                     }
                 }
@@ -772,10 +843,10 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
                 if (tid == 0) W.flag[0] = any_reset ? 1 : 0;
             }
             // a last partial round of at most one wave of pairs is wave 0's (it is done with S2 before the others finish)
-            if (any_rvo && more && tail_pairs <= CAGYM_WAVE && tid < tail_pairs) half_planes3<MT>(D, W, full_pairs + tid, M, MP, AS);
+            if (any_rvo && more && tail_pairs <= CAGYM_WAVE && tid < tail_pairs) half_planes3<MT>(D, W, full_pairs + tid, M, MP, AS, ko);
         } else if (any_rvo && more) {
             const int lim = tail_pairs <= CAGYM_WAVE ? full_pairs : nup;
-            for (int p = tid - CAGYM_WAVE; p < lim; p += NT - CAGYM_WAVE) half_planes3<MT>(D, W, p, M, MP, AS);
+            for (int p = tid - CAGYM_WAVE; p < lim; p += NT - CAGYM_WAVE) half_planes3<MT>(D, W, p, M, MP, AS, ko);
         }
         __syncthreads();
         STAMP(6);
@@ -786,13 +857,13 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
                 if (a < nagents) {
                     const int wl = (int)__umulhi((uint32_t)a, inv_m);
                     W.trvo[a] = live_rvo(W.tst[a], (a - wl * M) < W.wn[wl]);
-                    if (any_rvo) publish_pref_velocity3(W, a);
+                    if (any_rvo) ego_lp_inputs3<OBST>(D, W, a, M, AS, ko, inv_m);
                 }
             }
             for (int p = tid; p < nup; p += NT) pair_distances3<MT>(D, W, p, M, MP);
             __syncthreads();
             if (any_rvo && more)
-                for (int p = tid; p < nup; p += NT) half_planes3<MT>(D, W, p, M, MP, AS);
+                for (int p = tid; p < nup; p += NT) half_planes3<MT>(D, W, p, M, MP, AS, ko);
             __syncthreads();
         }
         STAMP(7);
@@ -819,14 +890,14 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
 // half-plane per lane (4096 worlds x 10 agents = 1024 workgroups = 4 per CU must be co-resident), 3 otherwise
 __host__ __device__ constexpr int cagym_min_waves3(int NT, int MT) { return NT > 256 ? 2 : ((MT > 0 && MT <= 10) ? 4 : 3); }
 
-template <int NT, int MT, int WPWT, bool AUTO_RESET>
-__global__ void __launch_bounds__(NT, cagym_min_waves3(NT, MT)) k_rollout3(CagymDev D, int n_steps, CagymOut out, int any_rvo) {
+template <int NT, int MT, int WPWT, bool AUTO_RESET, bool OBST>
+__global__ void __launch_bounds__(NT, OBST ? 2 : cagym_min_waves3(NT, MT)) k_rollout3(CagymDev D, int n_steps, CagymOut out, int any_rvo) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     WGTRACE(0);
 #ifdef CAGYM_WGTRACE
     if (threadIdx.x == 0 && blockIdx.x < CAGYM_WGTRACE_MAXWG) g_wgtrace[blockIdx.x * CAGYM_WGTRACE_W + 39] = 0;
 #endif
-    run_steps3<NT, MT, WPWT, AUTO_RESET>(D, smem, nullptr, out, n_steps, any_rvo != 0);
+    run_steps3<NT, MT, WPWT, AUTO_RESET, OBST>(D, smem, nullptr, out, n_steps, any_rvo != 0);
 #ifdef CAGYM_WGTRACE
     WGTRACE(38);
     if (threadIdx.x == 0 && blockIdx.x < CAGYM_WGTRACE_MAXWG)
@@ -835,8 +906,8 @@ __global__ void __launch_bounds__(NT, cagym_min_waves3(NT, MT)) k_rollout3(Cagym
 }
 
 // one step with external actions; the output buffers are NOT sliced (out_slice3 with t = 0 is the identity)
-template <int NT, int MT, int WPWT, bool AUTO_RESET>
-__global__ void __launch_bounds__(NT, cagym_min_waves3(NT, MT)) k_step3(CagymDev D, const float* ext, CagymOut out, int any_rvo) {
+template <int NT, int MT, int WPWT, bool AUTO_RESET, bool OBST>
+__global__ void __launch_bounds__(NT, OBST ? 2 : cagym_min_waves3(NT, MT)) k_step3(CagymDev D, const float* ext, CagymOut out, int any_rvo) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    run_steps3<NT, MT, WPWT, AUTO_RESET>(D, smem, ext, out, 1, any_rvo != 0);
+    run_steps3<NT, MT, WPWT, AUTO_RESET, OBST>(D, smem, ext, out, 1, any_rvo != 0);
 }

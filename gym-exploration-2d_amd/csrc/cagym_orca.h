@@ -474,3 +474,343 @@ __device__ inline void orca_lp_group(const float4* L, float4* P, int a, int j, i
     if (dbg) { dbg[0] = c_lp2; dbg[1] = c_lp3o; dbg[2] = c_lp3i; }
 #endif
 }
+
+
+// ---- static obstacles in the ORCA solve --------------------------------------------------------------------------------
+// RVOPolicy.find_next_action hands the world's rectangles to its private simulator (policies/RVOPolicy.py:56-57
+// sim.addObstacle, :45 sim.processObstacles at the first call only), timeHorizonObst = RVO_TIME_HORIZON
+// (:25-28).  Restated from RVO2 v2.0 (library absent: PARITY UNPINNED; bit-parity target is oracle/cagym_oracle.c, same
+// operation order): RVOSimulator::addObstacle, Agent::computeNeighbors / insertObstacleNeighbor and the obstacle half of
+// Agent::computeNewVelocity.  Stated deviation (as in the oracle): RVO2's obstacle BSP may split an edge that straddles
+// another edge's supporting line and fixes the order of equidistant edges by its traversal; here edges are never split
+// and equidistant edges keep (rectangle, edge) index order, which is what RVO2 itself does for a single rectangle.
+struct OrcaVertex {
+    float x, y, ux, uy;
+    bool convex;
+};
+
+// counter-clockwise polygon [(xu,yu), (xl,yu), (xl,yl), (xu,yl)] of test_cases.py:2496; vertex k of rect = xl, yl, xu, yu
+__device__ __forceinline__ OrcaVertex orca_rect_vertex(const double* rect, int k) {
+    const float xl = (float)rect[0], yl = (float)rect[1], xu = (float)rect[2], yu = (float)rect[3];
+    const int nx = (k + 1) & 3, pv = (k + 3) & 3;
+    const float X = (k == 0 || k == 3) ? xu : xl, Y = (k < 2) ? yu : yl;
+    const float Xn = (nx == 0 || nx == 3) ? xu : xl, Yn = (nx < 2) ? yu : yl;
+    const float Xp = (pv == 0 || pv == 3) ? xu : xl, Yp = (pv < 2) ? yu : yl;
+    OrcaVertex V;
+    const float ex = Xn - X, ey = Yn - Y;
+    const float inv = 1.0f / sqrtf(ex * ex + ey * ey);
+    V.x = X; V.y = Y;
+    V.ux = ex * inv; V.uy = ey * inv;
+    V.convex = detf(Xp - Xn, Yp - Yn, X - Xp, Y - Yp) >= 0.0f;  // leftOf(prev, this, next) >= 0
+    return V;
+}
+
+__device__ __forceinline__ float orca_dist_sq_point_segment(float ax, float ay, float bx, float by, float cx, float cy) {
+    const float r = ((cx - ax) * (bx - ax) + (cy - ay) * (by - ay)) / ((bx - ax) * (bx - ax) + (by - ay) * (by - ay));
+    if (r < 0.0f) return (cx - ax) * (cx - ax) + (cy - ay) * (cy - ay);
+    if (r > 1.0f) return (cx - bx) * (cx - bx) + (cy - by) * (cy - by);
+    const float qx = cx - (ax + r * (bx - ax)), qy = cy - (ay + r * (by - ay));
+    return qx * qx + qy * qy;
+}
+
+// One obstacle edge o1 -> o2 (pv = predecessor of o1) against the nl lines built so far (L[k * stride], k < nl).
+// Returns true and fills `out` when the edge contributes a half-plane.
+__device__ inline bool orca_obstacle_line(const OrcaVertex& o1, const OrcaVertex& o2, const OrcaVertex& pv, float px, float py,
+                                          float vx, float vy, float radius, float inv_tho, const float4* L, int stride, int nl,
+                                          float4& out) {
+    const float rp1x = o1.x - px, rp1y = o1.y - py, rp2x = o2.x - px, rp2y = o2.y - py;
+    for (int j = 0; j < nl; j++) {  // already covered by an earlier obstacle line?
+        const float4 lj = L[j * stride];
+        if (detf(inv_tho * rp1x - lj.x, inv_tho * rp1y - lj.y, lj.z, lj.w) - inv_tho * radius >= -RVO_EPS &&
+            detf(inv_tho * rp2x - lj.x, inv_tho * rp2y - lj.y, lj.z, lj.w) - inv_tho * radius >= -RVO_EPS)
+            return false;
+    }
+    const float dsq1 = rp1x * rp1x + rp1y * rp1y, dsq2 = rp2x * rp2x + rp2y * rp2y;
+    const float rsq = radius * radius;
+    const float ovx = o2.x - o1.x, ovy = o2.y - o1.y;
+    const float s = ((-rp1x) * ovx + (-rp1y) * ovy) / (ovx * ovx + ovy * ovy);
+    const float lx = -rp1x - s * ovx, ly = -rp1y - s * ovy;
+    const float dsq_line = lx * lx + ly * ly;
+    if (s < 0.0f && dsq1 <= rsq) {  // collision with the left vertex; ignored when non-convex
+        if (!o1.convex) return false;
+        const float nxv = -rp1y, nyv = rp1x, inv = 1.0f / sqrtf(nxv * nxv + nyv * nyv);
+        out = make_float4(0.0f, 0.0f, nxv * inv, nyv * inv);
+        return true;
+    } else if (s > 1.0f && dsq2 <= rsq) {  // collision with the right vertex; the neighbouring edge takes it otherwise
+        if (!(o2.convex && detf(rp2x, rp2y, o2.ux, o2.uy) >= 0.0f)) return false;
+        const float nxv = -rp2y, nyv = rp2x, inv = 1.0f / sqrtf(nxv * nxv + nyv * nyv);
+        out = make_float4(0.0f, 0.0f, nxv * inv, nyv * inv);
+        return true;
+    } else if (s >= 0.0f && s < 1.0f && dsq_line <= rsq) {  // collision with the segment
+        out = make_float4(0.0f, 0.0f, -o1.ux, -o1.uy);
+        return true;
+    }
+    // no collision: legs
+    float llx, lly, rlx, rly;
+    OrcaVertex a1 = o1, a2 = o2, left_nb = pv;  // obstacle1 / obstacle2 / obstacle1->prevObstacle_ after the substitutions
+    bool same = false;
+    if (s < 0.0f && dsq_line <= rsq) {  // viewed obliquely: the left vertex defines the velocity obstacle
+        if (!o1.convex) return false;
+        a2 = o1;
+        same = true;
+        const float leg1 = sqrtf(dsq1 - rsq);
+        llx = (rp1x * leg1 - rp1y * radius) / dsq1; lly = (rp1x * radius + rp1y * leg1) / dsq1;
+        rlx = (rp1x * leg1 + rp1y * radius) / dsq1; rly = (-rp1x * radius + rp1y * leg1) / dsq1;
+    } else if (s > 1.0f && dsq_line <= rsq) {  // viewed obliquely: the right vertex defines it
+        if (!o2.convex) return false;
+        a1 = o2;
+        same = true;
+        left_nb = o1;  // obstacle2->prevObstacle_
+        const float leg2 = sqrtf(dsq2 - rsq);
+        llx = (rp2x * leg2 - rp2y * radius) / dsq2; lly = (rp2x * radius + rp2y * leg2) / dsq2;
+        rlx = (rp2x * leg2 + rp2y * radius) / dsq2; rly = (-rp2x * radius + rp2y * leg2) / dsq2;
+    } else {  // usual situation
+        if (o1.convex) {
+            const float leg1 = sqrtf(dsq1 - rsq);
+            llx = (rp1x * leg1 - rp1y * radius) / dsq1; lly = (rp1x * radius + rp1y * leg1) / dsq1;
+        } else { llx = -o1.ux; lly = -o1.uy; }
+        if (o2.convex) {
+            const float leg2 = sqrtf(dsq2 - rsq);
+            rlx = (rp2x * leg2 + rp2y * radius) / dsq2; rly = (-rp2x * radius + rp2y * leg2) / dsq2;
+        } else { rlx = o1.ux; rly = o1.uy; }
+    }
+    // legs never point into a neighbouring edge of a convex vertex: the neighbour's cut-off line takes over
+    bool left_foreign = false, right_foreign = false;
+    if (a1.convex && detf(llx, lly, -left_nb.ux, -left_nb.uy) >= 0.0f) {
+        llx = -left_nb.ux; lly = -left_nb.uy;
+        left_foreign = true;
+    }
+    if (a2.convex && detf(rlx, rly, a2.ux, a2.uy) <= 0.0f) {
+        rlx = a2.ux; rly = a2.uy;
+        right_foreign = true;
+    }
+    const float lcx = inv_tho * (a1.x - px), lcy = inv_tho * (a1.y - py);  // cut-off centres
+    const float rcx = inv_tho * (a2.x - px), rcy = inv_tho * (a2.y - py);
+    const float cvx = rcx - lcx, cvy = rcy - lcy;
+    const float t = same ? 0.5f : ((vx - lcx) * cvx + (vy - lcy) * cvy) / (cvx * cvx + cvy * cvy);
+    const float t_left = (vx - lcx) * llx + (vy - lcy) * lly;
+    const float t_right = (vx - rcx) * rlx + (vy - rcy) * rly;
+    if ((t < 0.0f && t_left < 0.0f) || (same && t_left < 0.0f && t_right < 0.0f)) {  // left cut-off circle
+        const float wx = vx - lcx, wy = vy - lcy, inv = 1.0f / sqrtf(wx * wx + wy * wy);
+        const float uwx = wx * inv, uwy = wy * inv;
+        out = make_float4(lcx + radius * inv_tho * uwx, lcy + radius * inv_tho * uwy, uwy, -uwx);
+        return true;
+    } else if (t > 1.0f && t_right < 0.0f) {  // right cut-off circle
+        const float wx = vx - rcx, wy = vy - rcy, inv = 1.0f / sqrtf(wx * wx + wy * wy);
+        const float uwx = wx * inv, uwy = wy * inv;
+        out = make_float4(rcx + radius * inv_tho * uwx, rcy + radius * inv_tho * uwy, uwy, -uwx);
+        return true;
+    }
+    // left leg, right leg or cut-off line, whichever is closest to the velocity
+    float dc = INFINITY, dl = INFINITY, dr = INFINITY;
+    if (!(t < 0.0f || t > 1.0f || same)) {
+        const float qx = vx - (lcx + t * cvx), qy = vy - (lcy + t * cvy);
+        dc = qx * qx + qy * qy;
+    }
+    if (!(t_left < 0.0f)) {
+        const float qx = vx - (lcx + t_left * llx), qy = vy - (lcy + t_left * lly);
+        dl = qx * qx + qy * qy;
+    }
+    if (!(t_right < 0.0f)) {
+        const float qx = vx - (rcx + t_right * rlx), qy = vy - (rcy + t_right * rly);
+        dr = qx * qx + qy * qy;
+    }
+    float dx, dy, bx, by;
+    if (dc <= dl && dc <= dr) {  // cut-off line
+        dx = -a1.ux; dy = -a1.uy; bx = lcx; by = lcy;
+    } else if (dl <= dr) {  // left leg
+        if (left_foreign) return false;
+        dx = llx; dy = lly; bx = lcx; by = lcy;
+    } else {  // right leg
+        if (right_foreign) return false;
+        dx = -rlx; dy = -rly; bx = rcx; by = rcy;
+    }
+    out = make_float4(bx + radius * inv_tho * (-dy), by + radius * inv_tho * dx, dx, dy);
+    return true;
+}
+
+// Obstacle neighbours (nearest first) of one ego and their ORCA lines, written to L[k * stride], k < return value <= cap.
+// nbr: private scratch of the lane, `cap` entries (key = squared distance, id = 4 * rectangle + edge) at nbr_stride.
+// One lane per ego; every loop is bounded by 4 * n_obst.
+__device__ inline int orca_obstacle_lines(const double* rects, int n_obst, float px, float py, float vx, float vy, float radius,
+                                          float max_speed, float time_horizon_obst, float4* L, int stride, int cap,
+                                          float2* nbr, int nbr_stride) {
+    const float range = time_horizon_obst * max_speed + radius, range_sq = range * range;
+    int nn = 0;
+    for (int r = 0; r < n_obst; r++) {
+        for (int k = 0; k < 4; k++) {
+            const OrcaVertex o1 = orca_rect_vertex(rects + 4 * r, k), o2 = orca_rect_vertex(rects + 4 * r, (k + 1) & 3);
+            const float left = detf(o1.x - px, o1.y - py, o2.x - o1.x, o2.y - o1.y);  // leftOf(o1, o2, position)
+            const float ex = o2.x - o1.x, ey = o2.y - o1.y;
+            const float dsq_line = (left * left) / (ex * ex + ey * ey);
+            if (!(dsq_line < range_sq) || !(left < 0.0f)) continue;  // only from its right side (the agent can see it)
+            const float dsq = orca_dist_sq_point_segment(o1.x, o1.y, o2.x, o2.y, px, py);
+            if (!(dsq < range_sq)) continue;
+            if (nn >= cap) continue;  // cannot happen for an agent outside every rectangle (<= 2 visible edges each)
+            int i = nn++;  // Agent::insertObstacleNeighbor: insertion sort, strict <
+            while (i != 0 && dsq < nbr[(i - 1) * nbr_stride].x) {
+                nbr[i * nbr_stride] = nbr[(i - 1) * nbr_stride];
+                i--;
+            }
+            nbr[i * nbr_stride] = make_float2(dsq, __int_as_float(4 * r + k));
+        }
+    }
+    const float inv_tho = 1.0f / time_horizon_obst;
+    int nl = 0;
+    for (int q = 0; q < nn; q++) {
+        const int id = __float_as_int(nbr[q * nbr_stride].y);
+        const int r = id >> 2, k = id & 3;
+        const OrcaVertex o1 = orca_rect_vertex(rects + 4 * r, k), o2 = orca_rect_vertex(rects + 4 * r, (k + 1) & 3),
+                         pv = orca_rect_vertex(rects + 4 * r, (k + 3) & 3);
+        float4 ln;
+        if (orca_obstacle_line(o1, o2, pv, px, py, vx, vy, radius, inv_tho, L, stride, nl, ln)) {
+            L[nl * stride] = ln;
+            nl++;
+        }
+    }
+    return nl;
+}
+
+
+// ---- linearProgram2/3 on a GW-lane group with LPL half-planes per lane and protected obstacle lines ----------------------
+// Line q of the solve (q < no: obstacle line q, row q of the ego's column; q >= no: agent line q - no, row ko + q - no)
+// lives on lane q % GW, slot q / GW.  linearProgram3 keeps the obstacle lines as they are and projects only the agent
+// lines (RVO2: projLines(lines.begin(), lines.begin() + numObstLines)).  n = no + nn <= GW * LPL.  P: LPL * GW entries.
+template <int GW, int LPL>
+__device__ __forceinline__ uint64_t orca_group_mask(const bool (&v)[LPL], int gbase) {
+    const uint64_t gbits = (1ull << GW) - 1ull;
+    uint64_t m = 0;
+#pragma unroll
+    for (int c = 0; c < LPL; c++) m |= ((__ballot(v[c]) >> gbase) & gbits) << (c * GW);
+    return m;
+}
+template <int GW, int LPL>
+__device__ __forceinline__ bool orca_lp1_group_n(const float4 ln, const float4 (&mine)[LPL], const bool (&take)[LPL], float radius,
+                                                 float ox, float oy, bool dir_opt, float& rx, float& ry) {
+    const float dot = ln.x * ln.z + ln.y * ln.w;
+    const float disc = dot * dot + radius * radius - (ln.x * ln.x + ln.y * ln.y);
+    if (disc < 0.0f) return false;
+    const float sq = sqrtf(disc);
+    float tl = -dot - sq, tr = -dot + sq;
+    float ltl = -INFINITY, ltr = INFINITY;
+#pragma unroll
+    for (int c = 0; c < LPL; c++)
+        if (take[c]) orca_clip_by(ln, mine[c], ltl, ltr);
+    tl = fmaxf(tl, grp_max<GW>(ltl));
+    tr = fminf(tr, grp_min<GW>(ltr));
+    if (tl > tr) return false;
+    float t;
+    if (dir_opt) {
+        t = (ox * ln.z + oy * ln.w > 0.0f) ? tr : tl;
+    } else {
+        t = ln.z * (ox - ln.x) + ln.w * (oy - ln.y);
+        if (t < tl) t = tl;
+        else if (t > tr) t = tr;
+    }
+    rx = ln.x + t * ln.z;
+    ry = ln.y + t * ln.w;
+    return true;
+}
+template <int GW, int LPL>
+__device__ inline void orca_lp_group_n(const float4* L, float4* P, int a, int j, int no, int nn, int ko, float radius, float ox,
+                                       float oy, float& rx, float& ry, int stride, int* lp3_flag = nullptr) {
+    const int gbase = (threadIdx.x & 63) & ~(GW - 1);
+    const int n = no + nn;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 l[LPL];
+#pragma unroll
+    for (int c = 0; c < LPL; c++) {
+        const int q = j + c * GW;
+        l[c] = q < n ? L[(q < no ? q : ko + q - no) * stride + a] : zero4;
+    }
+    if (ox * ox + oy * oy > radius * radius) {
+        const float inv = 1.0f / sqrtf(ox * ox + oy * oy);
+        rx = ox * inv * radius;
+        ry = oy * inv * radius;
+    } else {
+        rx = ox;
+        ry = oy;
+    }
+    int fail = n;
+    for (int cur = 0; cur < n;) {  // cur grows by at least 1 per trip
+        bool v[LPL];
+#pragma unroll
+        for (int c = 0; c < LPL; c++) {
+            const int q = j + c * GW;
+            v[c] = q >= cur && q < n && detf(l[c].z, l[c].w, l[c].x - rx, l[c].y - ry) > 0.0f;
+        }
+        const uint64_t m = orca_group_mask<GW, LPL>(v, gbase);
+        if (!m) break;
+        const int i = __ffsll((unsigned long long)m) - 1;
+        const float4 li = L[(i < no ? i : ko + i - no) * stride + a];
+        bool take[LPL];
+#pragma unroll
+        for (int c = 0; c < LPL; c++) take[c] = j + c * GW < i;
+        if (!orca_lp1_group_n<GW, LPL>(li, l, take, radius, ox, oy, false, rx, ry)) {
+            fail = i;
+            break;
+        }
+        cur = i + 1;
+    }
+    float distance = 0.0f;
+    if (lp3_flag && fail < n && j == 0) *lp3_flag = 1;
+    for (int cur = fail; cur < n;) {
+        bool w[LPL];
+#pragma unroll
+        for (int c = 0; c < LPL; c++) {
+            const int q = j + c * GW;
+            w[c] = q >= cur && q < n && detf(l[c].z, l[c].w, l[c].x - rx, l[c].y - ry) > distance;
+        }
+        const uint64_t wm = orca_group_mask<GW, LPL>(w, gbase);
+        if (!wm) break;
+        const int i = __ffsll((unsigned long long)wm) - 1;
+        cur = i + 1;
+        const float4 li = L[(i < no ? i : ko + i - no) * stride + a];
+        // projected set: the obstacle lines as they are, then the agent lines before i projected onto line i.  The set is
+        // COMPACTED in RVO2 (skipped "parallel, same direction" lines leave no hole); order and membership are all that
+        // linearProgram2 depends on, so holes (have = false) are simply never selected here.
+        float4 p[LPL];
+        bool have[LPL];
+#pragma unroll
+        for (int c = 0; c < LPL; c++) {
+            const int q = j + c * GW;
+            have[c] = false;
+            p[c] = zero4;
+            if (q < no) {
+                p[c] = l[c];
+                have[c] = true;
+            } else if (q < i) {
+                have[c] = orca_project(li, l[c], p[c]);
+            }
+            if (have[c]) P[q] = p[c];
+        }
+        const int np = i > no ? i : no;  // projected lines occupy indices < max(i, no)
+        const float px = -li.w, py = li.z;
+        const float tx = rx, ty = ry;
+        float qx = px * radius, qy = py * radius;  // linearProgram2, directionOpt
+        bool failed = false;
+        for (int kcur = 0; kcur < np;) {
+            bool u[LPL];
+#pragma unroll
+            for (int c = 0; c < LPL; c++) {
+                const int q = j + c * GW;
+                u[c] = have[c] && q >= kcur && detf(p[c].z, p[c].w, p[c].x - qx, p[c].y - qy) > 0.0f;
+            }
+            const uint64_t um = orca_group_mask<GW, LPL>(u, gbase);
+            if (!um) break;
+            const int k = __ffsll((unsigned long long)um) - 1;
+            kcur = k + 1;
+            const float4 pk = P[k];
+            bool take[LPL];
+#pragma unroll
+            for (int c = 0; c < LPL; c++) take[c] = have[c] && j + c * GW < k;
+            if (!orca_lp1_group_n<GW, LPL>(pk, p, take, radius, px, py, true, qx, qy)) {
+                failed = true;
+                break;
+            }
+        }
+        if (failed) { rx = tx; ry = ty; }
+        else { rx = qx; ry = qy; }
+        distance = detf(li.z, li.w, li.x - rx, li.y - ry);
+    }
+}

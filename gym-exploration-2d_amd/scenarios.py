@@ -96,3 +96,72 @@ def heading_toward_goal(agents6):
     """Initial heading when none is given (agent.py:29-31)."""
     a = np.asarray(agents6, dtype=np.float64)
     return np.arctan2(a[..., 3] - a[..., 1], a[..., 2] - a[..., 0])
+
+
+def obstacle_worlds(N, M, K, seed=1234, n_agents_min=None):
+    """Worlds in the style of train_stage_2 (test_cases.py:2464-2572), vectorised: per world 2..K non-overlapping
+    axis-aligned rectangles (square of side U(1,2), or wall U(1,4) x (U(1,2) if wide else U(3,4)); upper corner U(-8,10)^2;
+    is_shape_valid :150-170), every agent starts at distance U(8,10) from the origin at a random angle with its goal at
+    the antipode, start and goal at least 1 m from every rectangle (is_pose_valid_with_obstacles :135-148) and 1.5 m
+    from every earlier start / goal (is_pose_valid :129-133); radius 0.5, pref_speed 1.  A different (batched) RNG stream
+    than the reference's.  Returns agents6 [N, M, 6], obstacles [N, K, 4] (xl, yl, xu, yu), n_obst [N], n_agents [N]
+    (M everywhere unless n_agents_min is given: U{n_agents_min..M} as :2534)."""
+    rng = np.random.default_rng(seed)
+    n_obst = rng.integers(2, K + 1, N).astype(np.int32)
+    obst = np.zeros((N, K, 4))
+    for k in range(K):
+        todo = np.nonzero(n_obst > k)[0]
+        tries = 0
+        while todo.size:
+            tries += 1
+            if tries > 200:  # no room left for another rectangle in these worlds: they keep the k they have
+                n_obst[todo] = k
+                break
+            n = todo.size
+            square = rng.uniform(size=n) < 0.5
+            sq = rng.uniform(1, 2, n)
+            wx = rng.uniform(1, 4, n)
+            wy = np.where(wx > 2, rng.uniform(1, 2, n), rng.uniform(3, 4, n))
+            sx, sy = np.where(square, sq, wx), np.where(square, sq, wy)
+            xu, yu = rng.uniform(-8, 10, n), rng.uniform(-8, 10, n)
+            xl, yl = xu - sx, yu - sy
+            ok = np.ones(n, dtype=bool)
+            for j in range(k):
+                o = obst[todo, j]
+                ok &= (o[:, 0] >= xu) | (xl >= o[:, 2]) | (o[:, 3] <= yl) | (yu <= o[:, 1])
+            w = todo[ok]
+            obst[w, k] = np.stack([xl[ok], yl[ok], xu[ok], yu[ok]], 1)
+            todo = todo[~ok]
+    a6 = np.zeros((N, M, 6))
+    a6[:, :, 4], a6[:, :, 5] = 1.0, 0.5
+
+    def clear(p, idx):  # 1 m from every rectangle of the world
+        o = obst[idx]
+        live = np.arange(K)[None, :] < n_obst[idx, None]
+        inside = (p[:, None, 0] < o[:, :, 2] + 1) & (p[:, None, 1] < o[:, :, 3] + 1) & (p[:, None, 0] > o[:, :, 0] - 1) & (p[:, None, 1] > o[:, :, 1] - 1)
+        return ~(inside & live).any(1)
+
+    for i in range(M):
+        todo = np.arange(N)
+        tries = 0
+        while todo.size:
+            tries += 1
+            if tries % 200 == 0:  # rectangles leave no admissible start/goal pair: such a world gives up its last rectangle
+                n_obst[todo] = np.maximum(n_obst[todo] - 1, 0)
+            if tries > 200 * (K + 2):
+                raise RuntimeError("obstacle_worlds: could not place agent %d in %d worlds" % (i, todo.size))
+            n = todo.size
+            d, ang = rng.uniform(8, 10, n), rng.uniform(-np.pi, np.pi, n)
+            s = np.stack([d * np.cos(ang), d * np.sin(ang)], 1)
+            ok = clear(s, todo) & clear(-s, todo)
+            for j in range(i):
+                ok &= np.hypot(*(s - a6[todo, j, 0:2]).T) >= 1.5
+                ok &= np.hypot(*(s - a6[todo, j, 2:4]).T) >= 1.5
+                ok &= np.hypot(*(-s - a6[todo, j, 0:2]).T) >= 1.5
+                ok &= np.hypot(*(-s - a6[todo, j, 2:4]).T) >= 1.5
+            w = todo[ok]
+            a6[w, i, 0:2], a6[w, i, 2:4] = s[ok], -s[ok]
+            todo = todo[~ok]
+    obst[np.arange(K)[None, :] >= n_obst[:, None]] = 0.0
+    n_agents = np.full(N, M, dtype=np.int32) if n_agents_min is None else rng.integers(n_agents_min, M + 1, N).astype(np.int32)
+    return a6, obst, n_obst, n_agents

@@ -35,7 +35,9 @@ enum { CAGYM_POL_STATIC = 0,   /* policies/StaticPolicy.py:9-12            a = (
        CAGYM_POL_EXTERNAL = 2, /* raw (speed, delta_heading) from ext_actions                  */
        CAGYM_POL_LEARNING = 3, /* policies/LearningPolicy.py:11-16         a = (v_pref*u0, 4*(2*u1-1))     */
        CAGYM_POL_CARRL = 4,    /* policies/CARRLPolicy.py:5-15             11-row table, index in ext[.,0] */
-       CAGYM_POL_RVO = 5,      /* policies/RVOPolicy.py:53-117             ORCA half-planes + 2-D LP       */
+       CAGYM_POL_RVO = 5,      /* policies/RVOPolicy.py:53-117             ORCA half-planes (other agents and, :56-57, the
+                                  world's rectangles) + 2-D LP; needs 2*max_obstacles + max_agents - 1 <= 32 (64 for
+                                  max_agents > 10) half-planes per ego and non-degenerate rectangles               */
        CAGYM_POL_GA3C = 6,     /* policies/GA3CCADRLPolicy.py:34-43        action supplied by cagym_ga3c_* */
        CAGYM_POL_IGMCTS = 7 }; /* policies/ig_mcts.py:79-109               (v, omega) supplied by planner  */
 
@@ -132,13 +134,13 @@ int cagym_step(void* env, const float* ext_actions, const cagym_outputs* out, vo
 
 /* cagym_step followed, in the same launch, by DummyVecEnv's auto-reset (exp/env_utils.py:29-31): a world whose
  * game_over fires restarts on its next scenario, its episode statistics are folded, and the observation written
- * for this step is the first one of the new episode (reward / flags / game_over are the terminal ones).
- * Does not produce laserscan for the restarted worlds' first observation when cfg.laserscan (call cagym_laserscan). */
+ * for this step -- OtherAgentsStates, scalar keys and, with cfg.laserscan, the laser scan (_get_obs runs every sensor,
+ * env.py:740-753) -- is the first one of the new episode (reward / flags / game_over are the terminal ones). */
 int cagym_step_autoreset(void* env, const float* ext_actions, const cagym_outputs* out, void* stream);
 
 /* n_steps consecutive step() calls in ONE launch for worlds whose agents are all driven internally
- * (Static / NonCooperative / RVO): state stays in registers, every step writes its outputs to slice
- * t of `out` ([T, ...] buffers; T = n_steps).  auto_reset != 0: a world whose game_over fires is
+ * (Static / NonCooperative / RVO): the agent records stay on chip, every step writes its outputs (laserscan
+ * [T, N, M, 16] included when cfg.laserscan) to slice t of `out` ([T, ...] buffers; T = n_steps).  auto_reset != 0: a world whose game_over fires is
  * reset onto its next scenario inside the kernel (what stable-baselines' DummyVecEnv does around the
  * reference env, exp/env_utils.py:29-31) and its episode statistics are accumulated. */
 int cagym_rollout(void* env, int n_steps, int auto_reset, const cagym_outputs* out, void* stream);

@@ -1,0 +1,115 @@
+"""cfg4 as a composition (BASELINE configs[3]): RVO agents among rectangles (obstacle ORCA half-planes), LaserScan in the
+fused step / rollout / auto-reset paths, GA3C-CADRL on agent 0.  HIP vs the CPU oracle on the same inputs.
+RVO arithmetic is PARITY UNPINNED against the absent rvo2 library (oracle = restatement of RVO2 v2.0, see
+oracle/cagym_oracle.c); the LaserScan and everything else is pinned by the reference-generated fixtures elsewhere."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+import golden_util as gu
+from oracle import oracle as orc
+from test_hip_parity import _compare_batch, _hip
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+scen = importlib.import_module("gym-exploration-2d_amd.scenarios")
+pytestmark = pytest.mark.gpu
+
+
+def _laser_close(hip, cpu, t):
+    a, b = hip.f("laserscan"), cpu.f("laserscan")
+    # a beam sample within 1e-9 of a raster cell border may fall on either side; count such disagreements, they must be rare
+    bad = np.abs(a - b) > 1e-6
+    assert bad.mean() <= 2e-4, ("laserscan", t, int(bad.sum()))
+
+
+@pytest.mark.parametrize("M,K", [(10, 10), (4, 6), (20, 8), (7, 5)])
+def test_rvo_among_obstacles_hip_matches_oracle(M, K):
+    """Every agent RVO, 2..K rectangles per world, LaserScan on every agent: states, masks, rewards, OAS and scans."""
+    N, T = 64, 60
+    a6, obst, n_obst, _ = scen.obstacle_worlds(N, M, K, seed=40 + M)
+    rng = np.random.default_rng(M)
+    n_agents = rng.integers(max(1, M - 4), M + 1, N).astype(np.int32)
+    coop = np.full((N, M), 0.5)
+    hip = _hip(N=N, M=M, max_obstacles=K, game_over_mode=1, laserscan=True)
+    cpu = orc.OracleEnv(N=N, M=M, max_obstacles=K, game_over_mode=1, laserscan=True)
+    for e in (hip, cpu):
+        e.set_scenario(a6, scen.POLICY_RVO, scen.DYN_UNICYCLE, n_agents=n_agents, coop=coop, obstacles=obst, n_obst=n_obst)
+        e.reset()
+    _compare_batch(hip, cpu, N, M, 0)
+    _laser_close(hip, cpu, 0)
+    for t in range(T):
+        hip.step()
+        cpu.step()
+        assert np.abs(hip.f("action") - cpu.f("action")).max() <= 2e-7, ("action", t)
+        _compare_batch(hip, cpu, N, M, t + 1, ftol=1e-7)
+        _laser_close(hip, cpu, t + 1)
+    # the obstacle lines did something: agents slowed down in front of walls (some actions below full speed without neighbours in the way)
+    assert (cpu.u("in_collision").sum()) <= 0.05 * n_agents.sum()
+
+
+def test_cfg4_composition_ga3c_agent0_rvo_others_obstacles_laserscan():
+    """BASELINE configs[3] in small: agent 0 GA3C-CADRL (action from the fused forward kernel), 9 RVO agents, rectangles,
+    LaserScan, game_over = agent 0 done, N = 64.  The oracle receives the same external action for agent 0."""
+    import torch
+    GA3C = importlib.import_module("gym-exploration-2d_amd.ga3c").GA3CCADRLPolicy
+    N, M, K, T = 64, 10, 10, 80
+    a6, obst, n_obst, _ = scen.obstacle_worlds(N, M, K, seed=77)
+    pol = np.full((N, M), scen.POLICY_RVO, dtype=np.int32)
+    pol[:, 0] = scen.POLICY_GA3C
+    coop = np.full((N, M), 0.5)
+    hip = _hip(N=N, M=M, max_obstacles=K, game_over_mode=0, laserscan=True)
+    cpu = orc.OracleEnv(N=N, M=M, max_obstacles=K, game_over_mode=0, laserscan=True)
+    for e in (hip, cpu):
+        e.set_scenario(a6, pol, scen.DYN_UNICYCLE, coop=coop, obstacles=obst, n_obst=n_obst)
+        e.reset()
+    policy = GA3C(hip.env)
+    ext = torch.zeros((N, M, 2), dtype=torch.float32, device=hip.env.device)
+    for t in range(T):
+        policy.act(ext)
+        ref_states = cpu.ga3c_states(max_observed=9)
+        got = policy.states().double().cpu().numpy()
+        assert np.abs(got[:, 0] - ref_states[:, 0]).max() <= 1e-5, t  # the network input of agent 0
+        hip.env.step(ext)
+        cpu.step(ext.double().cpu().numpy())
+        _compare_batch(hip, cpu, N, M, t + 1, ftol=1e-7)
+        _laser_close(hip, cpu, t + 1)
+    assert cpu.u("is_done")[:, 0].mean() > 0.3
+
+
+def test_rollout_and_autoreset_with_laserscan():
+    """cagym_rollout writes the [T, N, M, 16] scans; cagym_step_autoreset returns the first scan of the new episode for
+    a restarted world: both equal step() + reset(advance) + cagym_laserscan on the host side."""
+    import torch
+    N, M, K, T = 48, 10, 8, 260
+    S = 3 * N
+    a6, obst, n_obst, _ = scen.obstacle_worlds(S, M, K, seed=5)
+    pol = np.full((S, M), scen.POLICY_RVO, dtype=np.int32)
+    pol[:, 1] = scen.POLICY_NONCOOP
+    mk = lambda: _hip(N=N, M=M, max_obstacles=K, game_over_mode=1, laserscan=True, n_scenarios=S)
+    a, b, c = mk(), mk(), mk()
+    for e in (a, b, c):
+        e.set_scenario(a6, pol, scen.DYN_UNICYCLE, coop=np.full((S, M), 0.5), obstacles=obst, n_obst=n_obst)
+        e.reset()
+    traj = a.env.rollout(T, auto_reset=True)
+    assert traj["laserscan"].shape == (T, N, M, 16)
+    resets = 0
+    for t in range(T):
+        # b: one fused launch per step with auto-reset; c: plain step, then host-driven reset of the finished worlds
+        b.env.step(auto_reset=True)
+        c.env.step()
+        go = c.env.game_over.clone()
+        rew, flags = c.env.reward.clone(), c.env.flags.clone()
+        if bool(go.any()):
+            resets += int(go.sum())
+            c.env.reset(world_mask=go, advance_episode=True)
+        for k, ref in (("reward", rew), ("flags", flags), ("game_over", go)):
+            assert torch.equal(traj[k][t], ref), (k, t)
+            assert torch.equal(getattr(b.env, k), ref), (k, t)
+        assert torch.equal(traj["laserscan"][t], c.env.obs_laser), t
+        assert torch.equal(b.env.obs_laser, c.env.obs_laser), t
+        assert torch.equal(traj["other_agents_states"][t], c.env.obs_oas) and torch.equal(b.env.obs_oas, c.env.obs_oas), t
+        assert torch.equal(traj["ego"][t], c.env.obs_ego), t
+    assert resets > 0
+    assert float(traj["laserscan"].max()) > 0.0  # walls were seen
