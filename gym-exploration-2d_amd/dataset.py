@@ -2,7 +2,10 @@
 
 The reference's dataset creator (experiments/src/run_trajectory_dataset_creator.py:53-109) walks each agent's
 `global_state_history` (agent.py:217-232: rows [t, px, py, gx, gy, radius, pref_speed, vx, vy, speed, heading,
-a0, a1], one per step the agent took) and writes, per agent, a list of records
+a0, a1]) and writes, per agent, a list of records.  Row k is written by Agent.take_action during the agent's
+(k+1)-th step AFTER the move and BEFORE `t += dt` (agent.py:176-186, 198-201): position / velocity / heading after
+k+1 moves next to the time stamp k * dt; the initial state is never logged, a done agent logs nothing more, and
+main() keeps rows [:step_num] (:164-167).  Pinned by tests/golden/adapters.npz (add_traj run on a reference episode).
 
     {'time', 'pedestrian_goal_position', 'coop_coef', 'other_agents_pos', 'other_agents_vel',
      'pedestrian_state': {'position', 'velocity'}}
@@ -19,23 +22,28 @@ HISTORY_COLUMNS = ("t", "pos_x", "pos_y", "goal_x", "goal_y", "radius", "pref_sp
 
 
 def record_episode(env, max_steps=1000, actions=None):
-    """Step every world of `env` (freshly reset) until its game is over (no auto-reset) or max_steps.
-    Returns dict of numpy arrays: history [T+1, N, M, 13] (global_state_history rows), step_num [N, M] (rows of agent i
-    are history[:step_num+1, w, i]), n_agents [N], coop [N, M]."""
+    """Step every world of `env` (freshly reset) until every agent is done (no auto-reset) or max_steps.
+    Returns dict of numpy arrays: history [T, N, M, 13] in the reference's row convention (row k = state after step k+1,
+    time stamp of before it), step_num [N, M] (the rows of agent i are history[:step_num, w, i]), n_agents [N],
+    coop [N, M]."""
     rows = []
 
     def snap():
         st = env.state()
         cols = [st[k] for k in HISTORY_COLUMNS] + [st["action"][..., 0].double(), st["action"][..., 1].double()]
-        rows.append(torch.stack([c.double() for c in cols], dim=-1))
+        return torch.stack([c.double() for c in cols], dim=-1)
 
-    snap()
-    over = torch.zeros(env.N, dtype=torch.bool, device=env.device)
+    prev = snap()
     for _ in range(max_steps):
-        _, _, go, _ = env.step(actions)
-        snap()
-        over |= go.bool()
-        if bool(over.all()):
+        env.step(actions)
+        cur = snap()
+        row = cur.clone()
+        row[..., 0] = prev[..., 0]  # Agent._update_state_history runs before `self.t += dt`
+        rows.append(row)
+        prev = cur
+        st = env.state()
+        active = torch.arange(env.M, device=env.device)[None, :] < st["n_agents"][:, None]
+        if bool((((st["status"] & 8) != 0) | ~active).all()):  # CAGYM_FLAG_DONE for every agent of every world
             break
     torch.cuda.synchronize(env.device)
     st = env.state()
@@ -55,13 +63,13 @@ def to_reference_records(rec, world, dt=0.1, last_time=0.0):
     d = None
     for i in range(n):
         traj = []
-        max_ts = int(steps[i]) + 1  # global_state_history.shape[0]: one row per step taken, plus the initial one
+        max_ts = int(steps[i])  # global_state_history[:step_num]: one row per step the agent took
         for t in range(max_ts):
             opos, ovel = [], []
             for j in range(n):
                 if j == i:
                     continue
-                lj = int(steps[j]) + 1
+                lj = int(steps[j])
                 if t >= lj:  # the other agent finished earlier: last position, zero velocity (:73-75)
                     opos.append((H[lj - 1, j, 1], H[lj - 1, j, 2]))
                     ovel.append((0, 0))

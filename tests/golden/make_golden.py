@@ -477,18 +477,6 @@ def ga3c_states():
     print("%-28s          %8.1f KB" % ("ga3c_states", os.path.getsize(path) / 1024))
 
 
-if __name__ == "__main__" and "--dmcts-only" not in sys.argv and "--scenarios-only" not in sys.argv:
-    if "--ga3c-only" in sys.argv:
-        ga3c_states()
-        sys.exit(0)
-    if "--ig-only" not in sys.argv:
-        main()
-    ig_primitives()
-    if "--ig-only" not in sys.argv:
-        ga3c_states()
-        dmcts_reference()
-
-
 def dmcts_reference(n_seeds=6, n_steps=6):
     """Cumulative team reward of the reference's own Dec-MCTS loop (experiments/src/dmcts.py:50-95) on its
     default scenario IG_agent_crossing with a tiny planning budget, for a few np.random seeds.  The planner uses
@@ -527,9 +515,6 @@ def dmcts_reference(n_seeds=6, n_steps=6):
     print(np.array(out["cum_reward"])[:, -1])
 
 
-if "--dmcts-only" in sys.argv:
-    dmcts_reference()
-
 
 def scenario_statistics(n_worlds=400, n_agents=10):
     """Scenarios drawn by the reference's own train_agents_random_positions (test_cases.py:1362-1463), seeded with
@@ -558,5 +543,89 @@ def scenario_statistics(n_worlds=400, n_agents=10):
     print("%-28s          %8.1f KB" % ("scenario_stats", os.path.getsize(path) / 1024))
 
 
-if "--scenarios-only" in sys.argv:
-    scenario_statistics()
+def adapters():
+    """Fixtures for the two adapters either side of the hot path, produced by the reference's own
+    code: (a) the flat observation MultiagentFlattenDictWrapper.observation (envs/wrappers.py:38-46) makes of the env's
+    dict observation, at reset and after every step of one episode (4 agents in a 10-slot env: the absent agents' slots
+    are part of the vector); (b) the records add_traj (experiments/src/run_trajectory_dataset_creator.py:53-109) builds
+    from the agents' global_state_history of the same episode, flattened to arrays."""
+    import importlib.util
+    from gym_collision_avoidance.envs.wrappers import MultiagentFlattenDictWrapper
+    keys = ['dist_to_goal', 'rel_goal', 'radius', 'heading_ego_frame', 'heading_global_frame', 'pos_global_frame',
+            'pref_speed', 'num_other_agents', 'other_agents_states', 'use_ppo']
+    old_keys = list(Config.STATES_IN_OBS)
+    Config.STATES_IN_OBS = list(keys)
+    set_max_agents(10)
+    Config.EVALUATE_MODE, Config.HOMOGENEOUS_TESTING, Config.TRAIN_SINGLE_AGENT = True, True, False
+    M = 4
+    rng = np.random.default_rng(31)
+    a6 = scen.random_world(rng, M)
+    heading0 = scen.heading_toward_goal(a6)
+    pol = np.array([scen.POLICY_NONCOOP, scen.POLICY_NONCOOP, scen.POLICY_STATIC, scen.POLICY_NONCOOP], dtype=np.int32)
+    with rh.quiet():
+        agents = [Agent(a6[i, 0], a6[i, 1], a6[i, 2], a6[i, 3], a6[i, 5], a6[i, 4], np.float64(heading0[i]),
+                        POLICIES[int(pol[i])], UnicycleDynamics, [OtherAgentsStatesSensor], i) for i in range(M)]
+        for k, a in enumerate(agents):
+            a.policy.targetMap = None
+            a.cooperation_coef = 0.25 * (k + 1)
+        env = OracleEnv()
+        env.set_agents(agents)
+        obs = env.reset()
+        wrap = MultiagentFlattenDictWrapper(env, dict_keys=keys, max_num_agents=10)
+    flat = [np.asarray(wrap.observation(obs), dtype=np.float64)]
+    for _ in range(400):
+        with rh.quiet():
+            obs, rew, go, info = env.step({})
+        flat.append(np.asarray(wrap.observation(obs), dtype=np.float64))
+        if all(a.is_done for a in env.agents):
+            break
+    idx = {k: np.array([wrap.observation_indices[a][k] for a in range(10)]) for k in keys}
+    # (b) add_traj on the finished episode, exactly as the creator's main() prepares the agents (:164-167)
+    spec = importlib.util.spec_from_file_location(
+        "creator", os.path.join(rh.REF_ROOT, "gym_collision_avoidance/experiments/src/run_trajectory_dataset_creator.py"))
+    src = open(spec.origin).read()
+    ns = {"np": np}
+    start = src.index("def add_traj(")
+    end = src.index("file_dir_template =")
+    exec(compile(src[start:end], spec.origin, "exec"), ns)  # the function's own text, executed in place (module import pulls gym/tf/tqdm)
+    for a in env.agents:
+        a.global_state_history = a.global_state_history[:a.step_num]
+    trajs = []
+    last = ns["add_traj"](env.agents, trajs, env.dt_nominal, 5.0, None)
+    rec = {}
+    for i, tr in enumerate(trajs):
+        rec["traj%d__time" % i] = np.array([d["time"] for d in tr])
+        rec["traj%d__goal" % i] = np.array([d["pedestrian_goal_position"] for d in tr], dtype=np.float64)
+        rec["traj%d__coop" % i] = np.array([d["coop_coef"] for d in tr], dtype=np.float64)
+        rec["traj%d__pos" % i] = np.array([d["pedestrian_state"]["position"] for d in tr], dtype=np.float64)
+        rec["traj%d__vel" % i] = np.array([d["pedestrian_state"]["velocity"] for d in tr], dtype=np.float64)
+        rec["traj%d__other_pos" % i] = np.array([d["other_agents_pos"] for d in tr], dtype=np.float64)
+        rec["traj%d__other_vel" % i] = np.array([d["other_agents_vel"] for d in tr], dtype=np.float64)
+    path = os.path.join(HERE, "adapters.npz")
+    np.savez_compressed(path, agents6=a6, heading0=heading0, policy_id=pol, coop=np.array([a.cooperation_coef for a in env.agents]),
+                        keys=np.array(keys), flat=np.array(flat), n_traj=np.array(len(trajs)), last_time=np.array(last),
+                        step_num=np.array([a.step_num for a in env.agents]),
+                        **{"idx__" + k: v for k, v in idx.items()}, **rec)
+    Config.STATES_IN_OBS = old_keys
+    print("%-28s          %8.1f KB  (%d steps, flat width %d)" % ("adapters", os.path.getsize(path) / 1024, len(flat) - 1, flat[0].size))
+
+
+if __name__ == "__main__":
+    only = [a for a in sys.argv[1:] if a.endswith("-only")]
+    if "--dmcts-only" in only:
+        dmcts_reference()
+    elif "--scenarios-only" in only:
+        scenario_statistics()
+    elif "--ga3c-only" in only:
+        ga3c_states()
+    elif "--adapters-only" in only:
+        adapters()
+    elif "--ig-only" in only:
+        ig_primitives()
+    else:  # the whole recipe, end to end
+        main()
+        ig_primitives()
+        ga3c_states()
+        dmcts_reference()
+        scenario_statistics()
+        adapters()

@@ -23,10 +23,10 @@ def test_export_schema_and_consistency(tmp_path):
     trajs, last = ds.to_reference_records(rec, world=1)
     assert len(trajs) == 3  # one trajectory per agent of the world
     for i, traj in enumerate(trajs):
-        assert len(traj) == steps[1, i] + 1
+        assert len(traj) == steps[1, i]  # global_state_history[:step_num] (run_trajectory_dataset_creator.py:164-167)
         r0, r1 = traj[0], traj[-1]
         assert set(r0) == {"time", "pedestrian_goal_position", "coop_coef", "other_agents_pos", "other_agents_vel", "pedestrian_state"}
-        assert r0["time"] == 0.0 and abs(r1["time"] - 0.1 * steps[1, i]) < 1e-9 and r0["coop_coef"] == 0.5
+        assert r0["time"] == 0.0 and abs(r1["time"] - 0.1 * (steps[1, i] - 1)) < 1e-9 and r0["coop_coef"] == 0.5
         assert len(r0["other_agents_pos"]) == 2 and len(r0["other_agents_vel"]) == 2
         # consecutive positions differ by velocity * dt (unicycle: the stored velocity is the one that produced the move)
         for a, b in zip(traj[:-1], traj[1:]):
