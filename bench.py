@@ -73,7 +73,7 @@ def self_launch(args):
     return subprocess.call(cmd, env=env)
 
 
-def cpu_baseline(M, policy_id, seconds=12.0, worlds=2048, threads=None):
+def cpu_baseline(M, policy_id, seconds=12.0, worlds=2048, threads=None, config="cfg3"):
     """The CPU restatement (oracle, "port") timed on this host's cores: the world loop of cao_step is shared between
     OpenMP threads (worlds are independent), bounded sample."""
     import numpy as np
@@ -82,9 +82,25 @@ def cpu_baseline(M, policy_id, seconds=12.0, worlds=2048, threads=None):
     orc.build()
     want = threads or min(os.cpu_count() or 1, 16)
     threads = int(orc.lib().cao_set_threads(int(want)))  # the team size actually in force (omp_get_max_threads)
-    a6 = scen.random_worlds_fast(worlds, M, seed=99)
-    env = orc.OracleEnv(N=worlds, M=M, game_over_mode=1)
-    env.set_scenario(a6, policy_id, scen.DYN_UNICYCLE, coop=np.full((worlds, M), 0.5))
+    note = ""
+    if config in ("cfg4", "cfg5"):
+        K = 10 if config == "cfg4" else 8
+        worlds = 512
+        a6, ob, nob, _ = scen.obstacle_worlds(worlds, M, K, seed=99)
+        pol = np.full((worlds, M), scen.POLICY_RVO if config == "cfg4" else scen.POLICY_NONCOOP, dtype=np.int32)
+        if config == "cfg4":
+            pol[:, 0] = scen.POLICY_NONCOOP
+            note = " (agent 0 NonCooperative in place of the GA3C network, 9 RVO among rectangles, LaserScan on)"
+        else:
+            pol[:, :3] = scen.POLICY_NONCOOP
+            pol[:, 3:5] = scen.POLICY_STATIC
+            note = " (env part only: no planner)"
+        env = orc.OracleEnv(N=worlds, M=M, max_obstacles=K, game_over_mode=0 if config == "cfg4" else 1, laserscan=config == "cfg4")
+        env.set_scenario(a6, pol, scen.DYN_UNICYCLE, coop=np.full((worlds, M), 0.5), obstacles=ob, n_obst=nob)
+    else:
+        a6 = scen.random_worlds_fast(worlds, M, seed=99)
+        env = orc.OracleEnv(N=worlds, M=M, game_over_mode=1)
+        env.set_scenario(a6, policy_id, scen.DYN_UNICYCLE, coop=np.full((worlds, M), 0.5))
     env.reset()
     env.run(8)  # thread team start-up, page faults
     steps = 0
@@ -97,8 +113,8 @@ def cpu_baseline(M, policy_id, seconds=12.0, worlds=2048, threads=None):
             break
     return {"value": worlds * steps / el, "unit": "env-steps/s", "cores": threads, "kind": "port",
             "sample": "%d worlds x %d agents, %d steps, %.1f s, C oracle (oracle/cagym_oracle.c) with its world loop on "
-                      "%d OpenMP threads (omp_get_max_threads), finished worlds restart inside the C loop, same policy/scenario rule"
-                      % (worlds, M, steps, el, threads)}
+                      "%d OpenMP threads (omp_get_max_threads), finished worlds restart inside the C loop, same policy/scenario rule%s"
+                      % (worlds, M, steps, el, threads, note)}
 
 
 def main():
@@ -111,10 +127,6 @@ def main():
     if args.gpus != world_size:
         sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node %d, or without a launcher)"
                  % (args.gpus, world_size, args.gpus))
-    if args.config in ("cfg4", "cfg5"):
-        rows = importlib.import_module("tools.bench_rows")
-        return rows.main_from_bench(args)
-
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -137,49 +149,164 @@ def main():
     scen = importlib.import_module("gym-exploration-2d_amd.scenarios")
     stats_mod = importlib.import_module("gym-exploration-2d_amd.stats")
     BEnv = importlib.import_module("gym-exploration-2d_amd.batched_env").BatchedCollisionAvoidanceEnv
-    defaults = {"cfg2": (4096, 4, "noncoop"), "cfg3": (4096, 10, "rvo")}[args.config]
-    N = args.worlds or defaults[0]
+    defaults = {"cfg2": (4096, 4, "noncoop"), "cfg3": (4096, 10, "rvo"), "cfg4": (8192, 10, "rvo"), "cfg5": (2048, 20, "noncoop")}[args.config]
     M = args.agents or defaults[1]
     policy = args.policy or defaults[2]
     pol = scen.POLICY_RVO if policy == "rvo" else scen.POLICY_NONCOOP
-    S = args.pool_factor * N
-    env = BEnv(N, M, n_scenarios=S, game_over_mode="all", device=device)
-    if args.scenarios == "device":
-        env.generate_scenarios(seed=1234 + 7919 * rank, ego_policy=pol, other_policies=(pol, pol), p_b=0.0)
+    if args.config in ("cfg4", "cfg5"):
+        # BASELINE quotes these two on a FIXED number of worlds sharded over the GPUs (strong scaling)
+        total = args.worlds or defaults[0]
+        N = stats_mod.shard_worlds(total, rank, world_size)[1]
+        scaling = "strong"
     else:
-        a6 = scen.random_worlds_fast(S, M, seed=1234 + 7919 * rank)
-        env.set_scenarios(a6, pol, scen.DYN_UNICYCLE, coop=np.full((S, M), 0.5))
-    env.reset()
-
-    ROLL = max(1, min(args.roll, args.steps))
-    traj = env.alloc_rollout(ROLL)
+        N = args.worlds or defaults[0]  # per GPU (weak scaling)
+        scaling = "weak"
+    S = args.pool_factor * N
+    extra = {}
     side = torch.cuda.Stream(device=device) if world_size > 1 else None
     gathered = None
 
-    def run(n_steps):
+    def gather_stats(env):
         nonlocal gathered
-        done = 0
-        launches = 0
-        while done < n_steps:
-            k = min(ROLL, n_steps - done)
-            if args.per_step_launch:
-                for _ in range(k):
-                    env.step(auto_reset=True)
+        if world_size > 1:
+            # episode-stats all-gather on a side stream, overlapping the next launch
+            local = stats_mod.pack_episode_stats(env.episode_stats())
+            side.wait_stream(torch.cuda.current_stream(device))
+            local.record_stream(side)  # allocated on the main stream, read by the collective on the side stream
+            with torch.cuda.stream(side):
+                gathered = stats_mod.all_gather_episode_stats(local, total_worlds=None if scaling == "weak" else total)
+
+    if args.config in ("cfg2", "cfg3"):
+        env = BEnv(N, M, n_scenarios=S, game_over_mode="all", device=device)
+        if args.scenarios == "device":
+            env.generate_scenarios(seed=1234 + 7919 * rank, ego_policy=pol, other_policies=(pol, pol), p_b=0.0)
+        else:
+            a6 = scen.random_worlds_fast(S, M, seed=1234 + 7919 * rank)
+            env.set_scenarios(a6, pol, scen.DYN_UNICYCLE, coop=np.full((S, M), 0.5))
+        env.reset()
+        ROLL = max(1, min(args.roll, args.steps))
+        traj = env.alloc_rollout(ROLL)
+        balg = B_STATE + (B_OAS9 if M <= 10 else B_OAS19)
+        workload = ("%d worlds x %d agents per GPU, %s policy + OtherAgentsStates sensor, UnicycleDynamics, random-goal "
+                    "episodes with auto-reset (BASELINE configs[%d])"
+                    % (N, M, "RVO/ORCA on-device LP" if policy == "rvo" else "NonCooperative", 2 if args.config == "cfg3" else 1))
+        launch_mode = "cagym_step_autoreset per step" if args.per_step_launch else "cagym_rollout"
+        kernel_name = env.kernel_name(rollout=not args.per_step_launch, auto_reset=True)
+
+        def run(n_steps):
+            done = 0
+            launches = 0
+            while done < n_steps:
+                k = min(ROLL, n_steps - done)
+                if args.per_step_launch:
+                    for _ in range(k):
+                        env.step(auto_reset=True)
+                        launches += 1
+                else:
+                    env.rollout(k, auto_reset=True, out=traj)
                     launches += 1
-            else:
-                env.rollout(k, auto_reset=True, out=traj)
-                launches += 1
-            done += k
-            if world_size > 1:
-                # episode-stats all-gather on a side stream, overlapping the next launch
-                local = stats_mod.pack_episode_stats(env.episode_stats())
-                side.wait_stream(torch.cuda.current_stream(device))
-                local.record_stream(side)  # allocated on the main stream, read by the collective on the side stream
-                with torch.cuda.stream(side):
-                    gathered = stats_mod.all_gather_episode_stats(local)
-        if side is not None:
-            torch.cuda.current_stream(device).wait_stream(side)
-        return launches
+                done += k
+                gather_stats(env)
+            if side is not None:
+                torch.cuda.current_stream(device).wait_stream(side)
+            return launches
+    elif args.config == "cfg4":
+        # agent 0 GA3C-CADRL (state kernel + fused forward kernel per step) + 9 RVO agents among 2-10 rectangles,
+        # LaserScan on every agent (scanned inside the step launch), game over when agent 0 is done, auto-reset
+        GA3C = importlib.import_module("gym-exploration-2d_amd.ga3c").GA3CCADRLPolicy
+        K = 10
+        S = 2 * N
+        a6, ob, nob, _ = scen.obstacle_worlds(S, M, K, seed=1234 + 7919 * rank)
+        pol4 = np.full((S, M), scen.POLICY_RVO, dtype=np.int32)
+        pol4[:, 0] = scen.POLICY_GA3C
+        env = BEnv(N, M, n_scenarios=S, max_obstacles=K, laserscan=True, game_over_mode="agent0", device=device)
+        env.set_scenarios(a6, pol4, scen.DYN_UNICYCLE, coop=np.full((S, M), 0.5), obstacles=ob, n_obst=nob)
+        env.reset()
+        ga3c = GA3C(env)
+        ext = torch.zeros((N, M, 2), dtype=torch.float32, device=device)
+        balg = B_STATE + B_OAS9 + B_LASER + 11250.0 / M  # env kernel: + scan out + the world's bit-packed raster once per step
+        workload = ("%d worlds x %d agents%s: agent 0 GA3C-CADRL (fused LSTM-64 + 3 x FC-256 forward per step), 9 RVO/ORCA agents "
+                    "among 2-10 rectangles (obstacle half-planes), LaserScan + OtherAgentsStates on every agent, auto-reset "
+                    "(BASELINE configs[3])" % (N, M, " on this rank" if world_size > 1 else ""))
+        launch_mode = "per step: cagym_ga3c_state + cagym_ga3c_forward + cagym_step_autoreset (laser scan inside)"
+        kernel_name = env.kernel_name(rollout=False, auto_reset=True)
+
+        def run(n_steps):
+            for _ in range(n_steps):
+                ga3c.act(ext)
+                env.step(ext, auto_reset=True)
+            gather_stats(env)
+            if side is not None:
+                torch.cuda.current_stream(device).wait_stream(side)
+            return n_steps
+
+        def cfg4_extra():
+            def loop(fn, reps=50):
+                fn()
+                torch.cuda.synchronize(device)
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    fn()
+                torch.cuda.synchronize(device)
+                return (time.perf_counter() - t0) / reps
+            t_nn = loop(lambda: ga3c.act(ext))
+            t_env = loop(lambda: env.step(ext, auto_reset=True))
+            return {"ga3c_evals_per_s": N / t_nn, "ga3c_ms_per_step": 1e3 * t_nn, "ga3c_tflops_fp32": N * 0.67e6 / t_nn / 1e12,
+                    "env_kernel_ms_per_step": 1e3 * t_env,
+                    "env_kernel_hbm_frac": balg * N * M / t_env / (HBM_PEAK_GBS * 1e9)}
+        extra["cfg4"] = cfg4_extra
+    else:  # cfg5: env part (3 IG agents driven externally + 2 static targets + 15 NonCooperative) + planner primitives
+        IG = importlib.import_module("gym-exploration-2d_amd.ig").InfoGain
+        K = 8
+        a6, ob, nob, _ = scen.obstacle_worlds(S, M, K, seed=1234 + 7919 * rank)
+        pol5 = np.full((S, M), scen.POLICY_NONCOOP, dtype=np.int32)
+        pol5[:, :3] = scen.POLICY_IGMCTS
+        pol5[:, 3:5] = scen.POLICY_STATIC
+        dyn5 = np.full((S, M), scen.DYN_UNICYCLE, dtype=np.int32)
+        dyn5[:, :3] = scen.DYN_FIRSTORDER
+        env = BEnv(N, M, n_scenarios=S, max_obstacles=K, game_over_mode="all", device=device)
+        env.set_scenarios(a6, pol5, dyn5, obstacles=ob, n_obst=nob)
+        env.reset()
+        ext = torch.zeros((N, M, 2), dtype=torch.float32, device=device)
+        ext[:, :3, 0] = 2.0
+        balg = B_STATE + B_OAS19
+        workload = ("%d worlds x %d agents%s, env part: 3 information-gain agents (external (v, omega), FirstOrderDynamics), 2 static "
+                    "targets, 15 NonCooperative, rectangles, OtherAgentsStates [19, 10] (BASELINE configs[4]); the planner part is "
+                    "reported as visibility queries/s and roll-outs/s" % (N, M, " on this rank" if world_size > 1 else ""))
+        launch_mode = "cagym_step_autoreset per step"
+        kernel_name = env.kernel_name(rollout=False, auto_reset=True)
+
+        def run(n_steps):
+            for _ in range(n_steps):
+                env.step(ext, auto_reset=True)
+            gather_stats(env)
+            if side is not None:
+                torch.cuda.current_stream(device).wait_stream(side)
+            return n_steps
+
+        def cfg5_extra():
+            ig = IG(env)
+            rng = np.random.default_rng(0)
+            Q = N * 32
+            poses = torch.from_numpy(np.concatenate([rng.uniform(-12, 12, (Q, 2)), rng.uniform(-np.pi, np.pi, (Q, 1))], 1)).to(device)
+            world = torch.arange(Q, device=device, dtype=torch.int32) % N
+
+            def loop(fn, reps=10):
+                fn()
+                torch.cuda.synchronize(device)
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    fn()
+                torch.cuda.synchronize(device)
+                return (time.perf_counter() - t0) / reps
+            t_vis = loop(lambda: ig.visible_cells(poses, world))
+            Qr, nsims, H = N * 3, 10, 4  # experiments/src/dmcts.py budget: Nsims 10, horizon 4, xdt 5
+            zeros = torch.zeros((Qr, 60), dtype=torch.int64, device=device)
+            t_ro = loop(lambda: ig.rollouts(poses[:Qr], zeros, zeros, world[:Qr], torch.full((Qr,), H), torch.full((Qr,), 0.5), nsims, 7))
+            return {"visibility_queries_per_s": Q / t_vis, "rollouts_per_s_horizon4": Qr * nsims / t_ro,
+                    "rollout_visibility_queries_per_s": Qr * nsims * H / t_ro,
+                    "l2_hit_rate": None, "l2_hit_rate_source": "profiles/ (rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum pass), not measured in this run"}
+        extra["cfg5"] = cfg5_extra
 
     def barrier():
         if world_size > 1:
@@ -223,12 +350,10 @@ def main():
 
     st = stats_mod.summarize(gathered if gathered is not None else stats_mod.pack_episode_stats(env.episode_stats()))
     if rank == 0:
-        total_worlds = N * world_size
+        total_worlds = N * world_size if scaling == "weak" else total
         value = total_worlds * args.steps / elapsed
         steps_per_launch = args.steps / launches
         launch_ms = dev_ms / launches
-        balg = B_STATE + (B_OAS9 if M <= 10 else B_OAS19)
-        kernel_name = env.kernel_name(rollout=not args.per_step_launch, auto_reset=True)
         achieved = balg * N * M * steps_per_launch / (launch_ms * 1e-3) / 1e9
         # HBM bytes per launch from the PMC counters are NOT collected in this run (they need rocprofv3 --pmc passes);
         # the figure below replays profiles/ (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes) for the
@@ -250,16 +375,13 @@ def main():
         copy_gbs = 5 * 2 * (1 << 30) / (c0.elapsed_time(c1) * 1e-3) / 1e9
         del src, dst
         line = {
-            "metric": "env-steps/sec (whole node), 4096 worlds x 10 agents",
+            "metric": "env-steps/sec (whole node), %d worlds x %d agents" % (total_worlds if scaling == "strong" else N, M),
             "value": value, "unit": "env-steps/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%d worlds x %d agents per GPU, %s policy + OtherAgentsStates sensor, "
-                                   "UnicycleDynamics, random-goal episodes with auto-reset (BASELINE configs[%d])"
-                                   % (N, M, "RVO/ORCA on-device LP" if policy == "rvo" else "NonCooperative",
-                                      2 if args.config == "cfg3" else 1),
+            "config": {"workload": workload,
                        "worlds_per_gpu": N, "agents": M, "steps_per_launch": steps_per_launch,
-                       "launch_mode": "cagym_step_autoreset per step" if args.per_step_launch else "cagym_rollout",
+                       "launch_mode": launch_mode,
                        "parallelism": "worlds sharded x%d, no data-path collective" % world_size},
             "repeats": len(blocks), "timing": "median of %d timed blocks of %d steps" % (len(blocks), args.steps),
             "ms_per_step_min": 1e3 * walls[0] / args.steps, "ms_per_step_max": 1e3 * walls[-1] / args.steps,
@@ -278,8 +400,14 @@ def main():
                          "traffic_bytes_per_launch": None if traffic is None else traffic_per_agent_step * N * M * steps_per_launch},
             "episodes": st,
         }
+        for name, fn in extra.items():
+            line[name] = fn()
+        if args.config == "cfg4":  # the timed step holds three launches: the roofline object prices the env kernel alone
+            line["roofline"].update({"achieved": line["cfg4"]["env_kernel_hbm_frac"] * HBM_PEAK_GBS, "frac": line["cfg4"]["env_kernel_hbm_frac"],
+                                     "launch_ms": line["cfg4"]["env_kernel_ms_per_step"], "launch_ms_min": None, "launch_ms_max": None,
+                                     "note": "env kernel alone (cagym_step_autoreset incl. laser scan), timed in its own loop"})
         if not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(M, pol)
+            line["cpu_baseline"] = cpu_baseline(M, pol, config=args.config)
         print(json.dumps(line), flush=True)
     if world_size > 1:
         dist.barrier()

@@ -29,6 +29,7 @@ struct Env {
     double* sc_heading_buf = nullptr;
     IgDev G{};
     uint32_t* ig_any = nullptr;
+    int32_t* gen_failed = nullptr;  // device word: agents whose rejection loop hit max_tries (cagym_generate_scenarios)
     bool ig_ready = false;
     int any_rvo = 1;
     int obst_rvo = 0;    // RVO agents in worlds with rectangles: the kernels build obstacle half-planes (OBST instantiations)
@@ -376,7 +377,11 @@ int cagym_generate_scenarios(void* env, const cagym_gen_params* params, int32_t*
     G.nobst = const_cast<int32_t*>(D.sc_nobst);
     G.S = e->cfg.n_scenarios;
     G.M = M;
-    int32_t* d_failed = reinterpret_cast<int32_t*>(D.episode);  // scratch word: the episode counters are rewritten below
+    if (!e->gen_failed) {
+        int rcf = dalloc(e, &e->gen_failed, 1);
+        if (rcf != CAGYM_OK) return rcf;
+    }
+    int32_t* d_failed = e->gen_failed;
     HIPCHK(e, hipMemsetAsync(d_failed, 0, sizeof(int32_t), st));
     hipLaunchKernelGGL(k_generate_scenarios, dim3((G.S + 63) / 64), dim3(64), 0, st, G, P, d_failed);
     HIPCHK(e, hipGetLastError());

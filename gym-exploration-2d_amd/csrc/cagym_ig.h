@@ -223,6 +223,10 @@ __global__ void __launch_bounds__(128) k_ig_visible(IgDev G, const double* poses
                                                     double range, unsigned long long* masks) {
     __shared__ unsigned long long vis[IG_BEL];
     const int q = blockIdx.x, tid = threadIdx.x;
+    if (world[q] < 0 || world[q] >= G.N) {  // caller-supplied index out of range: empty set, nothing is read
+        for (int j = tid; j < IG_BEL; j += blockDim.x) masks[(size_t)q * IG_BEL + j] = 0ull;
+        return;
+    }
     const uint32_t* d2 = G.d2 + (size_t)ig_scenario(G, world[q]) * CAGYM_MAPD * CAGYM_MAPD;
     ig_visible_block(d2, poses[3 * q], poses[3 * q + 1], poses[3 * q + 2], fov, range, vis, tid, blockDim.x);
     for (int j = tid; j < IG_BEL; j += blockDim.x) masks[(size_t)q * IG_BEL + j] = vis[j];
@@ -278,6 +282,10 @@ __global__ void __launch_bounds__(256) k_ig_reward(IgDev G, const unsigned long 
     __shared__ unsigned long long m[IG_BEL];
     __shared__ double red[256];
     const int q = blockIdx.x, tid = threadIdx.x;
+    if (world[q] < 0 || world[q] >= G.N) {  // out-of-range world: zero reward
+        if (tid == 0) reward[q] = 0.0;
+        return;
+    }
     for (int j = tid; j < IG_BEL; j += blockDim.x) m[j] = masks[(size_t)q * IG_BEL + j];
     __syncthreads();
     double r = ig_reward_block(G.belief + (size_t)world[q] * IG_BEL * IG_BEL, m, red, tid, blockDim.x);
@@ -289,6 +297,11 @@ __global__ void __launch_bounds__(256) k_ig_next_pose(IgDev G, const double* pos
                                                       double dt, double* next, uint8_t* feasible) {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= Q) return;
+    if (world[q] < 0 || world[q] >= G.N) {  // out-of-range world: infeasible, pose unchanged
+        next[3 * q] = poses[3 * q]; next[3 * q + 1] = poses[3 * q + 1]; next[3 * q + 2] = poses[3 * q + 2];
+        feasible[q] = 0;
+        return;
+    }
     const uint32_t* d2 = G.d2 + (size_t)ig_scenario(G, world[q]) * CAGYM_MAPD * CAGYM_MAPD;
     double x = poses[3 * q], y = poses[3 * q + 1], th = poses[3 * q + 2];
     bool ok = ig_next_pose(d2, x, y, th, actions[2 * q], actions[2 * q + 1], xdt, dt, radius[q]);
@@ -312,6 +325,18 @@ __global__ void __launch_bounds__(128) k_ig_rollouts(IgDev G, const double* pose
     __shared__ double red[128];
     const int q = blockIdx.x / nsims, sim = blockIdx.x % nsims, tid = threadIdx.x;
     const int w = world[q];
+    if (w < 0 || w >= G.N) {  // out-of-range world: zero reward, no roll-out
+        if (tid == 0) {
+            rewards[(size_t)q * nsims + sim] = 0.0;
+            if (final_pose) {
+                double* fp = final_pose + ((size_t)q * nsims + sim) * 3;
+                fp[0] = pose0[3 * q]; fp[1] = pose0[3 * q + 1]; fp[2] = pose0[3 * q + 2];
+            }
+        }
+        if (actions) for (int t = tid; t < max_steps; t += blockDim.x) actions[((size_t)q * nsims + sim) * max_steps + t] = 255;
+        if (observed_out) for (int j = tid; j < IG_BEL; j += blockDim.x) observed_out[((size_t)q * nsims + sim) * IG_BEL + j] = 0ull;
+        return;
+    }
     const uint32_t* d2 = G.d2 + (size_t)ig_scenario(G, w) * CAGYM_MAPD * CAGYM_MAPD;
     for (int j = tid; j < IG_BEL; j += blockDim.x) obs[j] = observed0[(size_t)q * IG_BEL + j];
     __syncthreads();

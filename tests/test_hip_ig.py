@@ -111,3 +111,21 @@ def test_rollouts_match_oracle(setup):
                 assert abs(r - rew[q, s]) <= 1e-12 * max(1, abs(r))
                 moved += int((a != 255).any())
         assert moved > 0
+
+
+def test_out_of_range_world_index_is_harmless(setup):
+    """Caller-supplied world indices outside [0, N) read nothing: empty visibility set, zero reward, infeasible pose."""
+    import torch
+    z, env, ig = setup
+    poses = z["corridor__vis_poses"][:4]
+    world = np.array([0, -1, 7, 1])
+    m = _u64(ig.visible_cells(poses, world))
+    ok = _u64(ig.visible_cells(poses, np.array([0, 0, 0, 1])))
+    assert np.array_equal(m[0], ok[0]) and np.array_equal(m[3], ok[3]) and not m[1].any() and not m[2].any()
+    r = ig.mi_reward(ig.visible_cells(poses, np.array([0, 0, 0, 1])), world).cpu().numpy()
+    assert r[1] == 0.0 and r[2] == 0.0 and r[0] > 0.0
+    acts = np.tile([2.0, 0.0], (4, 1))
+    nxt, feas = ig.next_pose(poses, acts, world, np.full(4, 0.5))
+    assert not bool(feas[1]) and not bool(feas[2])
+    assert np.array_equal(nxt[1].cpu().numpy(), poses[1]) and np.array_equal(nxt[2].cpu().numpy(), poses[2])
+    torch.cuda.synchronize()
