@@ -584,6 +584,12 @@ int cagym_debug_stamps(unsigned long long* out16, int reset) {
 }
 #endif
 
+#ifdef CAGYM_WAVETRACE
+int cagym_debug_wavetrace(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wavetrace), sizeof(unsigned long long) * CAGYM_WT_STEPS * CAGYM_WT_POINTS * 8);
+}
+#endif
+
 #ifdef CAGYM_WGTRACE
 int cagym_debug_wgtrace(unsigned long long* out, int n_wg) {
     if (n_wg > CAGYM_WGTRACE_MAXWG) n_wg = CAGYM_WGTRACE_MAXWG;

@@ -77,6 +77,12 @@ __device__ __forceinline__ double clipd(double x, double lo, double hi) { return
 // util.py:27-32.  Non-finite / absurd inputs (outside any action space) take a closed form so a
 // wave can never spin: every loop in this file has an exit every lane reaches.
 __device__ __forceinline__ double wrap_angle(double a) {
+    if (fabs(a) < 3 * kPi) {
+        // at most one turn of either loop of util.py:27-32 (a - 2 pi >= -pi for a >= pi, a + 2 pi < pi for a < -pi): two
+        // selects instead of two loops; every angle the step produces (heading + one action) takes this path
+        const double lo = a - 2 * kPi, hi = a + 2 * kPi;
+        return a >= kPi ? lo : (a < -kPi ? hi : a);
+    }
     if (!(fabs(a) <= 64.0 * kPi)) {
         if (!isfinite(a)) return a;
         a = a - 2 * kPi * floor((a + kPi) / (2 * kPi));
@@ -172,11 +178,20 @@ __device__ __forceinline__ double carrl_heading(int k) {
     return (double)k * step + lo;
 }
 
+// A policy that already knows the direction of the move it asks for hands it over: unit vector (c, s) of the angle `ang`.
+// take_action then skips the fp64 sincos of the new heading hn when hn = ang + d with |d| < 1e-6 (the action went through
+// fp32, so d is ~1e-8): cos(ang + d) = c (1 - d^2/2) - s d, sin(ang + d) = s (1 - d^2/2) + c d, error d^3/6 < 2e-19,
+// below the half-ulp of any libm sincos.  The RVO policy does (its action IS atan2 of the fp32 move).
+struct HeadingHint {
+    double c, s, ang;
+    bool valid;
+};
+
 // Agent.take_action (agent.py:147-190) + dynamics/*.py.  `act` is the fp32 pair of env.py:289.
 // Returns whether the agent moved (false: it was already done).  EGO = false leaves Dynamics.update_ego_frame to the
 // caller (the phase-split kernels run it on otherwise idle lanes of the next pair phase; nothing below reads it).
 template <bool EGO = true>
-__device__ __forceinline__ bool take_action(Agent& A, float act0, float act1, double dt) {
+__device__ __forceinline__ bool take_action(Agent& A, float act0, float act1, double dt, const HeadingHint* hint = nullptr) {
     A.a0 = act0;  // all_actions row (env.py:289): zeros for an agent that is already done
     A.a1 = act1;
     if (A.st & (CAGYM_FLAG_AT_GOAL | CAGYM_FLAG_RAN_OUT_OF_TIME | CAGYM_FLAG_IN_COLLISION)) {  // agent.py:148-159
@@ -188,12 +203,13 @@ __device__ __forceinline__ bool take_action(Agent& A, float act0, float act1, do
     }
     double a0 = (double)act0, a1 = (double)act1;
     double h = A.h, speed, hn;
-    switch (ST_DYN(A.st)) {
+    const uint32_t dyn = ST_DYN(A.st);
+    if (dyn == CAGYM_DYN_UNICYCLE || dyn > CAGYM_DYN_FIRSTORDER) {  // the common model first: no walk through the switch
+        speed = a0;
+        hn = wrap_angle(a1 + h);
+    } else
+    switch (dyn) {
         default:
-        case CAGYM_DYN_UNICYCLE:
-            speed = a0;
-            hn = wrap_angle(a1 + h);
-            break;
         case CAGYM_DYN_MAXTURNRATE: {
             double tr = clipd(a1 / dt, -3.0, 3.0);
             speed = a0;
@@ -224,7 +240,28 @@ __device__ __forceinline__ bool take_action(Agent& A, float act0, float act1, do
             break;
     }
     double s, c;
-    sincos(hn, &s, &c);
+    bool need_trig = true;
+    if (speed == 0.0) {
+        // the agent turns on the spot: position and velocity are speed * (cos, sin) = 0 whatever the angle (only the sign of
+        // the zero could differ from the reference's 0 * cos(hn))
+        c = 1.0;
+        s = 0.0;
+        need_trig = false;
+    } else if (hint && hint->valid) {
+        double d = hn - hint->ang;  // both in [-pi, pi]: d is ~0 or ~+-2 pi
+        d -= (2 * kPi) * rint(d * (1.0 / (2 * kPi)));
+        if (fabs(d) < 1e-6) {
+            const double q = 1.0 - 0.5 * d * d;
+            c = hint->c * q - hint->s * d;
+            s = hint->s * q + hint->c * d;
+            need_trig = false;
+        }
+    }
+#ifdef CAGYM_EXPERIMENT_NOTRIG
+    if (need_trig) { c = 1.0; s = 0.0; }
+#else
+    if (need_trig) sincos(hn, &s, &c);
+#endif
     double dx = speed * c * dt, dy = speed * s * dt;
     A.px += dx;
     A.py += dy;

@@ -189,6 +189,8 @@ __device__ inline void step_core(const CagymDev& D, const WaveLds& W, LaneCtx& C
     publish_tile(W, A, lane);
     wave_sync();
     float a0 = 0.f, a1 = 0.f;
+    HeadingHint hint;
+    hint.valid = false;
     if (C.valid && C.active && !(A.st & CAGYM_FLAG_DONE)) {
         double d0 = 0.0, d1 = 0.0;
         switch (ST_POLICY(A.st)) {
@@ -204,14 +206,14 @@ __device__ inline void step_core(const CagymDev& D, const WaveLds& W, LaneCtx& C
             case CAGYM_POL_CARRL: d0 = 1.0; d1 = carrl_heading(ext ? (int)ext[2 * aidx] : 0); break;
             case CAGYM_POL_RVO: {
                 NbrTile T{W.tpx, W.tpy, W.tvx, W.tvy, W.tr};
-                orca_action(T, W.lines, W.lines + (M - 1) * 64, lane, C.base, C.n, C.slot, A, D.dt, D.maxnb, d0, d1);
+                orca_action(T, W.lines, W.lines + (M - 1) * 64, lane, C.base, C.n, C.slot, A, D.dt, D.maxnb, d0, d1, &hint);
                 break;
             }
         }
         a0 = (float)d0;
         a1 = (float)d1;
     }
-    if (C.valid && C.active) take_action(A, a0, a1, D.dt);
+    if (C.valid && C.active) take_action(A, a0, a1, D.dt, &hint);
     wave_sync();  // every lane is done reading the pre-move tile
     publish_tile(W, A, lane);
     wave_sync();

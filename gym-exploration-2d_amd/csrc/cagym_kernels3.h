@@ -63,6 +63,22 @@ __device__ unsigned long long g_wgtrace[CAGYM_WGTRACE_MAXWG * CAGYM_WGTRACE_W];
 #define WGTRACE_BUSY(cnt) do { } while (0)
 #endif
 
+// Third diagnostic build (-DCAGYM_WAVETRACE, tools/wave_trace.py): lane 0 of EVERY WAVE of one workgroup stamps s_memtime at
+// the marked points of the first 24 steps of a launch: which wave arrives last at each barrier (= the critical chain).
+#ifdef CAGYM_WAVETRACE
+#define CAGYM_WT_STEPS 24
+#define CAGYM_WT_POINTS 16
+#define CAGYM_WT_WG 7
+__device__ unsigned long long g_wavetrace[CAGYM_WT_STEPS * CAGYM_WT_POINTS * 8];
+#define WAVETRACE(t, point)                                                                                           \
+    do {                                                                                                              \
+        if ((threadIdx.x & 63) == 0 && blockIdx.x == CAGYM_WT_WG && (t) < CAGYM_WT_STEPS)                             \
+            g_wavetrace[((t) * CAGYM_WT_POINTS + (point)) * 8 + (threadIdx.x >> 6)] = __builtin_amdgcn_s_memtime();   \
+    } while (0)
+#else
+#define WAVETRACE(t, point) do { } while (0)
+#endif
+
 #ifndef CAGYM_GW10
 #define CAGYM_GW10 8  // lanes per ORCA LP group when M <= 10 (nn <= 9 half-planes)
 #endif
@@ -619,6 +635,7 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
         if (lagging) __builtin_amdgcn_s_setprio(3);
         else __builtin_amdgcn_s_setprio(1);
 #endif
+        WAVETRACE(t, 0);
         // ---- phase C: linearProgram2/3 of every busy ego on a GW-lane group (first waves) ------------------------------
         int lp_waves = 0;
         if (any_rvo) {
@@ -636,6 +653,7 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
             const int g = tid / GW, j = tid & (GW - 1);
             bool worked = false;
             STAMP(8);  // busy list
+            WAVETRACE(t, 1);
 #ifdef CAGYM_STAMPS
             int dbg[3] = {0, 0, 0};
 #endif
@@ -655,9 +673,14 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
                                                  vx, vy, AS, &W.flag[3]);
                     } else {
 #ifdef CAGYM_STAMPS
-                        orca_lp_group<GW, TWO>(W.sorted, W.lp3 + 2 * (tid & ~(GW - 1)), a, j, nn, rad, pv.x, pv.y, vx, vy, AS, &W.flag[3], dbg);
+                        orca_lp_group<GW, TWO, (MT > 0 ? MT - 1 : 0)>(W.sorted, W.lp3 + 2 * (tid & ~(GW - 1)), a, j, nn, rad, pv.x, pv.y, vx, vy, AS, &W.flag[3], dbg);
 #else
-                        orca_lp_group<GW, TWO>(W.sorted, W.lp3 + 2 * (tid & ~(GW - 1)), a, j, nn, rad, pv.x, pv.y, vx, vy, AS, &W.flag[3]);
+#ifdef CAGYM_WAVETRACE
+                        orca_lp_group<GW, TWO, (MT > 0 ? MT - 1 : 0)>(W.sorted, W.lp3 + 2 * (tid & ~(GW - 1)), a, j, nn, rad, pv.x, pv.y, vx, vy, AS, &W.flag[3], nullptr,
+                                                                  (blockIdx.x == CAGYM_WT_WG && t < CAGYM_WT_STEPS && base == 0) ? g_wavetrace + (size_t)t * CAGYM_WT_POINTS * 8 : nullptr);
+#else
+                        orca_lp_group<GW, TWO, (MT > 0 ? MT - 1 : 0)>(W.sorted, W.lp3 + 2 * (tid & ~(GW - 1)), a, j, nn, rad, pv.x, pv.y, vx, vy, AS, &W.flag[3]);
+#endif
 #endif
                     }
                     if (j == 0) W.lpc[a] = make_float2(vx, vy);
@@ -672,6 +695,7 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
                 if (tid == 0 && blockIdx.x == 0) { g_stamps[12] += m0; g_stamps[13] += m1; g_stamps[14] += m2; g_stamps[15] += cnt; }
             }
 #endif
+            WAVETRACE(t, 2);
             // a wave that solved programs publishes them: LDS operations of one wave complete in order, the release
             // makes the compiler keep that order
             if (__builtin_amdgcn_readfirstlane((int)(__ballot(worked) != 0ull)) && (tid & (CAGYM_WAVE - 1)) == 0)
@@ -688,9 +712,12 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
                     __builtin_amdgcn_s_sleep(1);
             }
             STAMP(2);
+            WAVETRACE(t, 3);
             if (s1_lane) {
                 A = lds3_load_agent(W, tid);
                 float a0 = 0.f, a1 = 0.f;
+                HeadingHint hint;
+                hint.valid = false;
                 if (!(A.st & CAGYM_FLAG_DONE)) {
                     double d0 = 0.0, d1 = 0.0;
                     switch (ST_POLICY(A.st)) {
@@ -706,16 +733,19 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
                         case CAGYM_POL_CARRL: d0 = 1.0; d1 = carrl_heading(ext ? (int)ext[2 * aidx] : 0); break;
                         case CAGYM_POL_RVO: {
                             const float2 v = W.lpc[tid];  // LP result, or the clipped preferred velocity of an ego that needed none
-                            orca_post(A, v.x, v.y, D.dt, d0, d1);
+                            orca_post(A, v.x, v.y, D.dt, d0, d1, &hint);
                             break;
                         }
                     }
                     a0 = (float)d0;
                     a1 = (float)d1;
                 }
-                moved = take_action<false>(A, a0, a1, D.dt);
+                asm volatile("" :: "v"(a0), "v"(a1));
+                WAVETRACE(t, 15);
+                moved = take_action<false>(A, a0, a1, D.dt, &hint);
             }
             STAMP(3);
+            WAVETRACE(t, 4);
         } else if (t > 0) {
 #ifndef CAGYM_NO_LAG_PRIORITY
             __builtin_amdgcn_s_setprio(0);
@@ -725,8 +755,10 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
             if (lagging) __builtin_amdgcn_s_setprio(3);
             else __builtin_amdgcn_s_setprio(1);
 #endif
+            WAVETRACE(t, 4);
         }
         __syncthreads();  // rows of step t-1 are out: the moved state may replace the old one
+        WAVETRACE(t, 5);
         if (s1_lane) {
             lds3_store_s1(W, A, tid);
             W.tmoved[tid] = moved ? 1 : 0;
@@ -737,24 +769,19 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
         if (tid == NT - 1) { W.flag[1] = 0; W.flag[2] = 0; W.flag[4] = W.flag[3]; W.flag[3] = 0; }
         __syncthreads();
         STAMP(4);
-        // ---- phase A: pair distances, collision tests, OAS sort keys, fp32 squared distances; the last wave first runs
-        //      Dynamics.update_ego_frame of the agents that moved and prepares the next step's LP inputs -------------------
+        WAVETRACE(t, 6);
+        // ---- phase A: pair distances, collision tests, OAS sort keys, fp32 squared distances; the last wave first prepares
+        //      the next step's LP inputs (Dynamics.update_ego_frame waits for phase B: nothing before the rows needs it) -------
         if (tid >= NT - CAGYM_WAVE) {
             const int a = tid - (NT - CAGYM_WAVE);
-            if (a < nagents) {
-                if (W.tmoved[a]) {
-                    Agent E;
-                    E.px = W.tpx[a]; E.py = W.tpy[a]; E.gx = W.tgx[a]; E.gy = W.tgy[a]; E.h = W.th[a];
-                    double prx, pry;
-                    update_ego_frame(E, prx, pry);
-                    W.tdg[a] = E.dg; W.the[a] = E.he; W.tprx[a] = prx; W.tpry[a] = pry;
-                }
-                if (any_rvo) ego_lp_inputs3<OBST>(D, W, a, M, AS, ko, inv_m);
-            }
+            if (a < nagents && any_rvo) ego_lp_inputs3<OBST>(D, W, a, M, AS, ko, inv_m);
+            WAVETRACE(t, 7);
         }
         for (int p = tid; p < nup; p += NT) pair_distances3<MT>(D, W, p, M, MP);
+        WAVETRACE(t, 8);
         __syncthreads();
         STAMP(5);
+        WAVETRACE(t, 9);
         // ---- phase B: wave 0 = S2 (_compute_rewards env.py:502-567, _check_which_agents_done :711-738, auto-reset);
         //      waves 1.. = ORCA half-planes of step t+1 (wave 0 takes the pairs beyond their lanes afterwards) ----------------
         const bool more = t + 1 < n_steps;
@@ -841,6 +868,16 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
                 }
                 W.tst[tid] = S.st;
                 if (tid == 0) W.flag[0] = any_reset ? 1 : 0;
+                // Dynamics.update_ego_frame (dynamics/Dynamics.py:14-28) of the agents S1 moved: only the observation rows
+                // and the next S1 read it, and wave 0 is otherwise idle here until the half-plane lanes are done.  A world
+                // that was just reset got its ego frame from init_agent.
+                if (W.tmoved[tid] && !(AUTO_RESET && C.valid && go)) {
+                    Agent E;
+                    E.px = W.tpx[tid]; E.py = W.tpy[tid]; E.gx = W.tgx[tid]; E.gy = W.tgy[tid]; E.h = W.th[tid];
+                    double prx, pry;
+                    update_ego_frame(E, prx, pry);
+                    W.tdg[tid] = E.dg; W.the[tid] = E.he; W.tprx[tid] = prx; W.tpry[tid] = pry;
+                }
             }
             // a last partial round of at most one wave of pairs is wave 0's (it is done with S2 before the others finish)
             if (any_rvo && more && tail_pairs <= CAGYM_WAVE && tid < tail_pairs) half_planes3<MT>(D, W, full_pairs + tid, M, MP, AS, ko);
@@ -848,8 +885,10 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
             const int lim = tail_pairs <= CAGYM_WAVE ? full_pairs : nup;
             for (int p = tid - CAGYM_WAVE; p < lim; p += NT - CAGYM_WAVE) half_planes3<MT>(D, W, p, M, MP, AS, ko);
         }
+        WAVETRACE(t, 10);
         __syncthreads();
         STAMP(6);
+        WAVETRACE(t, 11);
         // ---- rare: a world restarted on its next scenario -> everything derived from the old episode is rebuilt -------------
         if (AUTO_RESET && W.flag[0]) {
             if (tid >= NT - CAGYM_WAVE) {
@@ -867,6 +906,7 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
             __syncthreads();
         }
         STAMP(7);
+        WAVETRACE(t, 12);
         WGTRACE(2 + t);
     }
     // ---- epilogue: observation of the last step on every wave, agent records -> HBM ------------------------------------------

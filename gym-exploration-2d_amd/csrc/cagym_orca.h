@@ -158,44 +158,36 @@ __device__ __forceinline__ OrcaPair orca_pair(float pex, float pey, float vex, f
     float cr = re + ro, crsq = cr * cr;
     OrcaPair g;
     g.d2 = d2;
-    if (d2 > crsq) {
-        float wx = rvx - inv_th * rpx, wy = rvy - inv_th * rpy;
-        float wlsq = wx * wx + wy * wy;
-        float dp1 = wx * rpx + wy * rpy;
-        if (dp1 < 0.0f && dp1 * dp1 > crsq * wlsq) {
-            float wl = sqrtf(wlsq);
-            float inv = 1.0f / wl;
-            float uwx = wx * inv, uwy = wy * inv;
-            g.zx = uwy;
-            g.zy = -uwx;
-            float s = cr * inv_th - wl;
-            g.ux = s * uwx;
-            g.uy = s * uwy;
-        } else {
-            float leg = sqrtf(d2 - crsq);
-            float inv = 1.0f / d2;
-            if (detf(rpx, rpy, wx, wy) > 0.0f) {
-                g.zx = (rpx * leg - rpy * cr) * inv;
-                g.zy = (rpx * cr + rpy * leg) * inv;
-            } else {
-                g.zx = -((rpx * leg + rpy * cr) * inv);
-                g.zy = -((-rpx * cr + rpy * leg) * inv);
-            }
-            float dp2 = rvx * g.zx + rvy * g.zy;
-            g.ux = dp2 * g.zx - rvx;
-            g.uy = dp2 * g.zy - rvy;
-        }
-    } else {
-        float inv_ts = 1.0f / time_step;
-        float wx = rvx - inv_ts * rpx, wy = rvy - inv_ts * rpy;
-        float wl = sqrtf(wx * wx + wy * wy);
-        float inv = 1.0f / wl;
-        float uwx = wx * inv, uwy = wy * inv;
+    // The three cases of Agent::computeNewVelocity (cut-off circle, legs, already colliding) share one sqrt and one
+    // reciprocal: lanes of a wave take different cases all the time, so the work common to them is done once, with
+    // selects, and each case keeps exactly its own expressions (same operands, same order: results are unchanged).
+    const bool collide = !(d2 > crsq);
+    const float k = collide ? 1.0f / time_step : inv_th;  // 1 / timeStep in the colliding case, 1 / timeHorizon otherwise
+    const float wx = rvx - k * rpx, wy = rvy - k * rpy;
+    const float wlsq = wx * wx + wy * wy;
+    const float dp1 = wx * rpx + wy * rpy;
+    const bool circle = collide || (dp1 < 0.0f && dp1 * dp1 > crsq * wlsq);
+    const float sq = sqrtf(circle ? wlsq : d2 - crsq);  // |w|, or the leg length
+    const float inv = 1.0f / (circle ? sq : d2);
+    if (circle) {
+        const float uwx = wx * inv, uwy = wy * inv;
         g.zx = uwy;
         g.zy = -uwx;
-        float s = cr * inv_ts - wl;
+        const float s = cr * k - sq;
         g.ux = s * uwx;
         g.uy = s * uwy;
+    } else {
+        const float leg = sq;
+        if (detf(rpx, rpy, wx, wy) > 0.0f) {
+            g.zx = (rpx * leg - rpy * cr) * inv;
+            g.zy = (rpx * cr + rpy * leg) * inv;
+        } else {
+            g.zx = -((rpx * leg + rpy * cr) * inv);
+            g.zy = -((-rpx * cr + rpy * leg) * inv);
+        }
+        const float dp2 = rvx * g.zx + rvy * g.zy;
+        g.ux = dp2 * g.zx - rvx;
+        g.uy = dp2 * g.zy - rvy;
     }
     return g;
 }
@@ -208,7 +200,8 @@ __device__ __forceinline__ float4 orca_line(float pex, float pey, float vex, flo
 }
 
 // Agent::update (fp32) and the fp64 tail of RVOPolicy.find_next_action (RVOPolicy.py:91-106).
-__device__ inline void orca_post(const Agent& A, float nvx, float nvy, double dt, double& out_speed, double& out_dh) {
+__device__ inline void orca_post(const Agent& A, float nvx, float nvy, double dt, double& out_speed, double& out_dh,
+                                 HeadingHint* hint = nullptr) {
     const float time_step = (float)dt;
     float npx = (float)A.px + nvx * time_step, npy = (float)A.py + nvy * time_step;  // Agent::update, fp32
     double dpx = (double)npx - A.px, dpy = (double)npy - A.py;                      // back in Python, fp64
@@ -217,7 +210,19 @@ __device__ inline void orca_post(const Agent& A, float nvx, float nvy, double dt
     double nh = ang1;
     if (nh < 0) nh += 2 * kPi;
     double dh = wrap_angle(nh - A.h);
-    double speed = 1 / dt * norm2(dpx, dpy);
+    const double dpn = norm2(dpx, dpy);
+    double speed = 1 / dt * dpn;
+    if (hint) {  // the move's own direction: the unicycle's new heading is this angle up to the fp32 rounding of dh
+        // 1 / |dp| by v_rsq_f64 + two Newton steps (relative error ~1e-16: the hint's own budget is d^3/6 ~ 1e-19 + this)
+        const double q = dot2(dpx, dpy, dpx, dpy);
+        double inv = __builtin_amdgcn_rsq(q);
+        inv = inv * (1.5 - 0.5 * q * inv * inv);
+        inv = inv * (1.5 - 0.5 * q * inv * inv);
+        hint->valid = dpn > 1e-9;
+        hint->c = dpx * inv;
+        hint->s = dpy * inv;
+        hint->ang = ang1;
+    }
     if (fabs(dh) > kPi / 6) {
         dh = (dh > 0 ? 1.0 : (dh < 0 ? -1.0 : 0.0)) * (kPi / 6);
         speed = 0.;
@@ -228,17 +233,18 @@ __device__ inline void orca_post(const Agent& A, float nvx, float nvy, double dt
 
 // LP2 (+LP3) on the nn sorted lines of `lane`, then Agent::update and RVOPolicy.py:91-106.
 __device__ inline void orca_solve(const float4* L, float4* P, int lane, int nn, const OrcaEgo& E, const Agent& A,
-                                  double dt, double& out_speed, double& out_dh) {
+                                  double dt, double& out_speed, double& out_dh, HeadingHint* hint = nullptr) {
     float nvx, nvy;
     int fail = orca_lp2(L, lane, nn, E.max_speed, E.pvx, E.pvy, false, nvx, nvy);
     if (fail < nn) orca_lp3(L, P, lane, nn, fail, E.max_speed, nvx, nvy);
-    orca_post(A, nvx, nvy, dt, out_speed, out_dh);
+    orca_post(A, nvx, nvy, dt, out_speed, out_dh, hint);
 }
 
 // RVOPolicy.find_next_action for the agent on `lane`; base = first lane of its world, n = agents in
 // the world, i = own slot.  L, P: LDS line arrays [maxnb][64].  Returns (speed, delta_heading).
 __device__ inline void orca_action(const NbrTile& T, float4* L, float4* P, int lane, int base, int n, int i,
-                                   const Agent& A, double dt, int maxnb, double& out_speed, double& out_dh) {
+                                   const Agent& A, double dt, int maxnb, double& out_speed, double& out_dh,
+                                   HeadingHint* hint = nullptr) {
     const OrcaEgo E = orca_ego(A, dt);
     // neighbour selection: nearest first, ties in index order, at most maxNeighbors (Agent::insertAgentNeighbor).
     // rank by counting == the insertion sort's result; ranks >= maxNeighbors are dropped.
@@ -259,7 +265,7 @@ __device__ inline void orca_action(const NbrTile& T, float4* L, float4* P, int l
         L[rank * CAGYM_WAVE + lane] = orca_line(E.px, E.py, E.vx, E.vy, E.r, E.c, E.time_step, T.px[base + j],
                                                 T.py[base + j], T.vx[base + j], T.vy[base + j], T.r[base + j]);
     }
-    orca_solve(L, P, lane, nn, E, A, dt, out_speed, out_dh);
+    orca_solve(L, P, lane, nn, E, A, dt, out_speed, out_dh, hint);
 }
 
 // ---- linearProgram2 + linearProgram3 of one ego on a GW-lane group (GW = 4, 8 or 16) ---------------------------
@@ -385,16 +391,24 @@ __device__ __forceinline__ bool orca_project(const float4 li, const float4 lj, f
 #else
 #define LPCOUNT(x) do { } while (0)
 #endif
-template <int GW, bool TWO>
+// ROWS: compile-time row count of the ego's column (M - 1) or 0: lanes j < ROWS load their first half-plane without
+// waiting for nn (a stale row is never looked at: every use is guarded by j < nn).
+template <int GW, bool TWO, int ROWS = 0>
 __device__ inline void orca_lp_group(const float4* L, float4* P, int a, int j, int nn, float radius, float ox, float oy,
-                                     float& rx, float& ry, int stride, int* lp3_flag = nullptr, int* dbg = nullptr) {
+                                     float& rx, float& ry, int stride, int* lp3_flag = nullptr, int* dbg = nullptr,
+                                     unsigned long long* wt = nullptr) {
 #ifdef CAGYM_STAMPS
     int c_lp2 = 0, c_lp3o = 0, c_lp3i = 0;
+#endif
+#ifdef CAGYM_WAVETRACE
+#define LPWT(k) do { if (wt && (threadIdx.x & 63) == 0) wt[(k) * 8 + (threadIdx.x >> 6)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define LPWT(k) do { } while (0)
 #endif
     const int gbase = (threadIdx.x & 63) & ~(GW - 1);
     const uint64_t gbits = (1ull << GW) - 1ull;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float4 l0 = j < nn ? L[j * stride + a] : zero4;
+    const float4 l0 = (ROWS >= GW || j < nn) ? L[j * stride + a] : zero4;
     const float4 l1 = j + GW < nn ? L[(j + GW) * stride + a] : zero4;
     if (ox * ox + oy * oy > radius * radius) {
         const float inv = 1.0f / sqrtf(ox * ox + oy * oy);
@@ -404,6 +418,8 @@ __device__ inline void orca_lp_group(const float4* L, float4* P, int a, int j, i
         rx = ox;
         ry = oy;
     }
+    asm volatile("" :: "v"(l0.x), "v"(rx));
+    LPWT(13);
     // linearProgram2.  The reference walks the lines in order and projects onto each violated one; between two
     // projections the result does not change, so "the next violated line at or after cur" is one parallel test
     // (lane j tests its half-planes) + a find-first-set.  The groups of a wave then run linearProgram1 in lockstep,
@@ -426,6 +442,7 @@ __device__ inline void orca_lp_group(const float4* L, float4* P, int a, int j, i
     // linearProgram3 (rare).  Same scan-and-jump: the next line at or after `cur` that is violated by more than
     // `distance`, then linearProgram2 (directionOpt) over the projected lines, again by scan-and-jump.
     float distance = 0.0f;
+    LPWT(14);
     if (lp3_flag && fail < nn && j == 0) *lp3_flag = 1;  // this workgroup is in a crowd: its step is the long one
     for (int cur = fail; cur < nn;) {
         const bool w0 = j >= cur && j < nn && detf(l0.z, l0.w, l0.x - rx, l0.y - ry) > distance;

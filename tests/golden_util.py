@@ -25,7 +25,7 @@ def load_cases(group):
 
 def all_groups():
     return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLD, "*.npz"))
-                  if not os.path.basename(p).startswith(("ig_", "ga3c", "scenario_")))  # episode fixtures only
+                  if not os.path.basename(p).startswith(("ig_", "ga3c", "scenario_", "adapters")))  # episode fixtures only
 
 
 def game_over_mode(cfg):
