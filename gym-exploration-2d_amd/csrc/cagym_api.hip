@@ -26,6 +26,7 @@ struct Env {
     std::string err;
     bool scenarios_set = false;
     double* sc_obst = nullptr;
+    float4* sc_obst_prep = nullptr;
     double* sc_heading_buf = nullptr;
     IgDev G{};
     uint32_t* ig_any = nullptr;
@@ -128,11 +129,13 @@ inline int n_wg2(const Env* e) {
     const int wpw = wpw_spec(e) ? wpw_spec(e) : CAGYM_WAVE / M;
     return (e->cfg.n_worlds + wpw - 1) / wpw;
 }
-inline size_t lds3_bytes(const Env* e, bool obst) {
+// obst: the OBST instantiation (worlds may hold rectangles); lines: RVO agents among them (obstacle half-plane rows)
+inline size_t lds3_bytes(const Env* e, bool obst, bool lines) {
     const int M = e->cfg.max_agents;
-    return cagym_lds3_bytes(M, cagym_as(M, wpw_spec(e)), spec2(e).nt, obst ? 2 * e->cfg.max_obstacles : 0, obst ? 4 : 2);
+    return cagym_lds3_bytes(M, cagym_as(M, wpw_spec(e)), spec2(e).nt, (obst && lines) ? 2 * e->cfg.max_obstacles : 0, obst ? 4 : 2);
 }
-inline size_t lds3_bytes(const Env* e) { return lds3_bytes(e, e->obst_rvo != 0); }
+inline bool has_map(const Env* e) { return e->cfg.max_obstacles > 0; }
+inline size_t lds3_bytes(const Env* e) { return lds3_bytes(e, has_map(e), e->obst_rvo != 0); }
 // LP group width of the handle's specialisation (run_steps3)
 inline int lp_group_width(const Env* e) {
     const int mt = spec2(e).mt;
@@ -219,9 +222,10 @@ int cagym_create(const cagym_config* cfg, void** env_out) {
     if (cfg->max_obstacles > 0) {
         A(dalloc(e, &dmap, S * CAGYM_MAPD * CAGYM_MAPW));
         A(dalloc(e, &e->sc_obst, S * (size_t)cfg->max_obstacles * 4));
+        A(dalloc(e, &e->sc_obst_prep, S * (size_t)cfg->max_obstacles * 4));
     }
     D.sc_agents6 = d6; D.sc_heading0 = nullptr; D.sc_coop = dcoop; D.sc_policy = dpol; D.sc_dyn = ddyn;
-    D.sc_nagents = dna; D.sc_nobst = dno; D.map_bits = dmap; D.sc_obst = e->sc_obst;
+    D.sc_nagents = dna; D.sc_nobst = dno; D.map_bits = dmap; D.sc_obst = e->sc_obst; D.sc_obst_prep = e->sc_obst_prep;
     A(dalloc(e, &D.px, NM)); A(dalloc(e, &D.py, NM)); A(dalloc(e, &D.vx, NM)); A(dalloc(e, &D.vy, NM));
     A(dalloc(e, &D.heading, NM)); A(dalloc(e, &D.heading_ego, NM)); A(dalloc(e, &D.dist_goal, NM));
     A(dalloc(e, &D.time_rem, NM)); A(dalloc(e, &D.t, NM)); A(dalloc(e, &D.gx, NM)); A(dalloc(e, &D.gy, NM));
@@ -253,7 +257,8 @@ int cagym_create(const cagym_config* cfg, void** env_out) {
             const char* w = getenv("CAGYM_WPW10");  // diagnostics
             if (w && (w[0] == '4' || w[0] == '5')) e->wpw10 = w[0] - '0';
         }
-        int lds3 = (int)lds3_bytes(e, false), lds3_obst = (int)lds3_bytes(e, true);
+        int lds3 = (int)lds3_bytes(e, false, false), lds3_obst = (int)lds3_bytes(e, true, true);
+        if (lds3_obst > 160 * 1024) lds3_obst = (int)lds3_bytes(e, true, false);  // too many rectangles for RVO agents: refused at set_scenarios
         if (e->generation == 3 && lds3 > 160 * 1024) e->generation = 1;
 #define SETATTR(NT, MT, WP) set_lds_attr3<NT, MT, WP>(lds3, lds3_obst)
         CAGYM_DISPATCH2(e, SETATTR);
@@ -305,12 +310,13 @@ int cagym_set_scenarios(void* env, const double* agents6, const double* heading0
         bool any_obst = false;
         for (size_t sc = 0; sc < S; sc++) any_obst |= no[sc] > 0;
         e->obst_rvo = (any_obst && e->any_rvo) ? 1 : 0;
+        e->D.ko = e->obst_rvo ? 2 * e->cfg.max_obstacles : 0;
         if (e->obst_rvo) {
             const int K = e->cfg.max_obstacles, gw = lp_group_width(e);
             const Spec2 sp = spec2(e);
             const int as = cagym_as((int)M, sp.wpw);
             if (e->generation != 3) return fail(e, CAGYM_E_UNSUPPORTED, "RVO agents among obstacles need the generation-3 kernels");
-            if (2 * K + (int)M - 1 > 4 * gw || (size_t)2 * K * as * 8 > (size_t)4 * sp.nt * 16 || lds3_bytes(e, true) > 160 * 1024)
+            if (2 * K + (int)M - 1 > 4 * gw || (size_t)2 * K * as * 8 > (size_t)4 * sp.nt * 16 || lds3_bytes(e, true, true) > 160 * 1024)
                 return fail(e, CAGYM_E_UNSUPPORTED, "too many rectangles per world for RVO agents at this max_agents (2 * max_obstacles + max_agents - 1 half-planes per ego)");
             if (obstacles)
                 for (size_t sc = 0; sc < S; sc++)
@@ -337,9 +343,38 @@ int cagym_set_scenarios(void* env, const double* agents6, const double* heading0
     HIPCHK(e, hipMemcpyAsync(const_cast<int32_t*>(D.sc_nagents), na.data(), S * sizeof(int32_t), hipMemcpyHostToDevice, st));
     HIPCHK(e, hipMemcpyAsync(const_cast<double*>(D.sc_coop), cp.data(), SM * sizeof(double), hipMemcpyHostToDevice, st));
     HIPCHK(e, hipMemcpyAsync(const_cast<int32_t*>(D.sc_nobst), no.data(), S * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    std::vector<float> prep;  // staged until the stream synchronisation below
     if (e->cfg.max_obstacles > 0) {
-        if (obstacles)
+        if (obstacles) {
             HIPCHK(e, hipMemcpyAsync(e->sc_obst, obstacles, S * (size_t)e->cfg.max_obstacles * 4 * sizeof(double), hipMemcpyHostToDevice, st));
+            // RVOSimulator::addObstacle per rectangle (vertices narrowed to float as Cython does): unit directions
+            // normalize(next - this) = v * (1.0f / |v|) and convexity leftOf(prev, this, next) >= 0, in plain IEEE fp32
+            const size_t K = (size_t)e->cfg.max_obstacles;
+            prep.assign(S * K * 16, 0.0f);
+            for (size_t r = 0; r < S * K; r++) {
+                const float xl = (float)obstacles[4 * r], yl = (float)obstacles[4 * r + 1], xu = (float)obstacles[4 * r + 2], yu = (float)obstacles[4 * r + 3];
+                const float X[4] = {xu, xl, xl, xu}, Y[4] = {yu, yu, yl, yl};
+                float* q = prep.data() + 16 * r;
+                q[0] = xl; q[1] = yl; q[2] = xu; q[3] = yu;
+                uint32_t convex = 0;
+                for (int k = 0; k < 4; k++) {
+                    const int nx = (k + 1) & 3, pv = (k + 3) & 3;
+                    const volatile float ex = X[nx] - X[k], ey = Y[nx] - Y[k];
+                    const volatile float sq = ex * ex;
+                    const volatile float sq2 = ey * ey;
+                    const volatile float len2 = sq + sq2;
+                    const volatile float inv = 1.0f / sqrtf(len2);
+                    q[4 + 2 * k] = ex * inv;
+                    q[5 + 2 * k] = ey * inv;
+                    const volatile float a0 = X[pv] - X[nx], a1 = Y[pv] - Y[nx], b0 = X[k] - X[pv], b1 = Y[k] - Y[pv];
+                    const volatile float m0 = a0 * b1;
+                    const volatile float m1 = a1 * b0;
+                    if (m0 - m1 >= 0.0f) convex |= 1u << k;
+                }
+                memcpy(&q[12], &convex, 4);
+            }
+            HIPCHK(e, hipMemcpyAsync(e->sc_obst_prep, prep.data(), prep.size() * sizeof(float), hipMemcpyHostToDevice, st));
+        }
         hipLaunchKernelGGL(k_rasterize, dim3((unsigned)S), dim3(256), 0, st, e->sc_obst, D.sc_nobst, e->cfg.max_obstacles,
                            const_cast<uint32_t*>(D.map_bits));
         HIPCHK(e, hipGetLastError());
@@ -388,6 +423,7 @@ int cagym_generate_scenarios(void* env, const cagym_gen_params* params, int32_t*
     D.sc_heading0 = nullptr;  // toward the goal (agent.py:29-31)
     e->any_rvo = (P.ego_policy == CAGYM_POL_RVO || P.policy_a == CAGYM_POL_RVO || P.policy_b == CAGYM_POL_RVO) ? 1 : 0;
     e->obst_rvo = 0;  // the generator draws free-space worlds
+    e->D.ko = 0;
     if (e->cfg.max_obstacles > 0) {  // free space: empty rasters
         hipLaunchKernelGGL(k_rasterize, dim3((unsigned)G.S), dim3(256), 0, st, e->sc_obst, D.sc_nobst, e->cfg.max_obstacles,
                            const_cast<uint32_t*>(D.map_bits));
@@ -440,7 +476,7 @@ int cagym_step(void* env, const float* ext_actions, const cagym_outputs* out, vo
         const size_t lds3 = lds3_bytes(e);
 #define STEP3(NT, MT, WP)                                                                                                        \
     do {                                                                                                                     \
-        if (e->obst_rvo) hipLaunchKernelGGL((k_step3<NT, MT, WP, false, true>), dim3(n_wg2(e)), dim3(NT), lds3, st, e->D, ext_actions, o, e->any_rvo); \
+        if (has_map(e)) hipLaunchKernelGGL((k_step3<NT, MT, WP, false, true>), dim3(n_wg2(e)), dim3(NT), lds3, st, e->D, ext_actions, o, e->any_rvo); \
         else hipLaunchKernelGGL((k_step3<NT, MT, WP, false, false>), dim3(n_wg2(e)), dim3(NT), lds3, st, e->D, ext_actions, o, e->any_rvo);       \
     } while (0)
         CAGYM_DISPATCH2(e, STEP3);
@@ -464,7 +500,7 @@ int cagym_step_autoreset(void* env, const float* ext_actions, const cagym_output
         const size_t lds3 = lds3_bytes(e);
 #define STEP3(NT, MT, WP)                                                                                                        \
     do {                                                                                                                     \
-        if (e->obst_rvo) hipLaunchKernelGGL((k_step3<NT, MT, WP, true, true>), dim3(n_wg2(e)), dim3(NT), lds3, st, e->D, ext_actions, o, e->any_rvo); \
+        if (has_map(e)) hipLaunchKernelGGL((k_step3<NT, MT, WP, true, true>), dim3(n_wg2(e)), dim3(NT), lds3, st, e->D, ext_actions, o, e->any_rvo); \
         else hipLaunchKernelGGL((k_step3<NT, MT, WP, true, false>), dim3(n_wg2(e)), dim3(NT), lds3, st, e->D, ext_actions, o, e->any_rvo);       \
     } while (0)
         CAGYM_DISPATCH2(e, STEP3);
@@ -492,9 +528,9 @@ int cagym_rollout(void* env, int n_steps, int auto_reset, const cagym_outputs* o
         const dim3 g(n_wg2(e));
 #define ROLL3(NT, MT, WP)                                                                                              \
     do {                                                                                                           \
-        if (auto_reset && e->obst_rvo) hipLaunchKernelGGL((k_rollout3<NT, MT, WP, true, true>), g, dim3(NT), lds3, st, e->D, n_steps, o, e->any_rvo); \
+        if (auto_reset && has_map(e)) hipLaunchKernelGGL((k_rollout3<NT, MT, WP, true, true>), g, dim3(NT), lds3, st, e->D, n_steps, o, e->any_rvo); \
         else if (auto_reset) hipLaunchKernelGGL((k_rollout3<NT, MT, WP, true, false>), g, dim3(NT), lds3, st, e->D, n_steps, o, e->any_rvo); \
-        else if (e->obst_rvo) hipLaunchKernelGGL((k_rollout3<NT, MT, WP, false, true>), g, dim3(NT), lds3, st, e->D, n_steps, o, e->any_rvo); \
+        else if (has_map(e)) hipLaunchKernelGGL((k_rollout3<NT, MT, WP, false, true>), g, dim3(NT), lds3, st, e->D, n_steps, o, e->any_rvo); \
         else hipLaunchKernelGGL((k_rollout3<NT, MT, WP, false, false>), g, dim3(NT), lds3, st, e->D, n_steps, o, e->any_rvo);         \
     } while (0)
         CAGYM_DISPATCH2(e, ROLL3);

@@ -437,20 +437,29 @@ __device__ __forceinline__ float laserscan_beam(const uint32_t* map, double px, 
     const double ang0 = b == 15 ? kPi : (double)b * astep + (-kPi);
     double sa, ca;
     sincos(ang0 + h, &sa, &ca);
-    int count = 0, last = -1;
+    // all 16 raster words of the beam are requested before the first one is looked at (16 gathers in flight instead of
+    // one after the other: the raster is L2-resident, the latency is what costs)
+    uint32_t word[16];
+    int bit[16];
+#pragma unroll
     for (int k = 0; k < 16; k++) {
         double rg = 0.0 + (double)k * rstep;
         double x = px + rg * ca, y = py + rg * sa;
         int gx, gy;
-        bool hit = false;
-        if (map && world_to_cell(x, y, gx, gy) && map_bit(map, gx, gy)) {
-            bool masked = false;
-            if (ego_in) {
-                double dx = (double)(gy - egy), dy = (double)(gx - egx);
-                masked = dx * dx + dy * dy < r2;
-            }
-            hit = !masked;
+        bool in = map && world_to_cell(x, y, gx, gy);
+        bool masked = false;
+        if (in && ego_in) {
+            double dx = (double)(gy - egy), dy = (double)(gx - egx);
+            masked = dx * dx + dy * dy < r2;
         }
+        in = in && !masked;
+        bit[k] = in ? (gy & 31) : -1;
+        word[k] = in ? map[gx * CAGYM_MAPW + (gy >> 5)] : 0u;
+    }
+    int count = 0, last = -1;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const bool hit = bit[k] >= 0 && ((word[k] >> (bit[k] & 31)) & 1u);
         count += hit ? 1 : 0;
         if (count == 1) last = k;
     }

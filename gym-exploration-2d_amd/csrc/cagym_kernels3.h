@@ -160,6 +160,8 @@ struct Lds3 {
     int* nobl;     // [AS] obstacle half-planes of the ego (rows 0 .. nobl-1 of its column of `sorted`)
     int* wn;       // [32] agents per world of this workgroup
     int* wsc;      // [32] scenario of the world's current episode (rectangles, raster)
+    int* wnob;     // [32] rectangles of that scenario
+    float4* rect;  // [worlds x Kobs x 4] the worlds' prepared rectangles (OBST only), staged at episode start
     int* flag;     // [8]  0: a world was reset this step   1: OAS row chunks claimed   2: LP waves finished
                    //      3/4: some ego needed linearProgram3 this / the previous step
     float2* lpv;   // [AS] preferred (optimisation) velocity of each ego
@@ -178,12 +180,13 @@ struct Lds3 {
 };
 
 __host__ __device__ inline size_t cagym_lds3_head(int AS) {
-    return (size_t)20 * AS * 8 + AS * 8 + (size_t)6 * AS * 4 + 64 * 4 + 8 * 4 + (size_t)2 * AS * 8 + (size_t)3 * AS * 4;
+    return (size_t)20 * AS * 8 + AS * 8 + (size_t)6 * AS * 4 + 96 * 4 + 8 * 4 + (size_t)2 * AS * 8 + (size_t)3 * AS * 4;
 }
 // ko: rows of `sorted` reserved for obstacle lines; lpl: half-planes per lane of an LP group
 __host__ __device__ inline size_t cagym_lds3_bytes(int M, int AS, int NT, int ko = 0, int lpl = 2) {
     const size_t MP = cagym_mp(M);
-    return a16(cagym_lds3_head(AS)) + a16(AS * MP * 4) + (size_t)(ko + M - 1) * AS * 16 + (size_t)lpl * NT * 16 + 2 * AS * MP * 8 + a16(AS * MP);
+    return a16(cagym_lds3_head(AS)) + a16(AS * MP * 4) + (size_t)(ko + M - 1) * AS * 16 + (size_t)lpl * NT * 16 + 2 * AS * MP * 8 + a16(AS * MP) +
+           (size_t)(AS / M) * (ko / 2) * 64;  // staged rectangles: worlds x Kobs x 4 float4
 }
 
 __device__ __forceinline__ Lds3 carve_lds3(unsigned char* smem, int M, int AS, int NT, int ko = 0, int lpl = 2) {
@@ -208,7 +211,8 @@ __device__ __forceinline__ Lds3 carve_lds3(unsigned char* smem, int M, int AS, i
     W.nobl = W.busy + AS;
     W.wn = W.nobl + AS;
     W.wsc = W.wn + 32;
-    W.flag = W.wsc + 32;
+    W.wnob = W.wsc + 32;
+    W.flag = W.wnob + 32;
     unsigned char* u = smem + a16(cagym_lds3_head(AS));
     W.dsq = reinterpret_cast<float*>(u);
     u += a16(AS * MP * 4);
@@ -219,7 +223,18 @@ __device__ __forceinline__ Lds3 carve_lds3(unsigned char* smem, int M, int AS, i
     W.keys = reinterpret_cast<double*>(u);
     W.gap = W.keys + AS * MP;
     W.hit = reinterpret_cast<uint8_t*>(W.gap + AS * MP);
+    W.rect = reinterpret_cast<float4*>(reinterpret_cast<unsigned char*>(W.hit) + a16(AS * MP));
     return W;
+}
+
+// the prepared rectangles (and their count) of every world of the workgroup: HBM -> LDS, all lanes; W.wsc must be visible
+__device__ __forceinline__ void stage_rects3(const CagymDev& D, const Lds3& W, int wpw, int worlds_valid) {
+    const int per = D.Kobs * 4;
+    for (int q = threadIdx.x; q < wpw * per; q += blockDim.x) {
+        const int wl = q / per;
+        if (wl < worlds_valid) W.rect[q] = D.sc_obst_prep[(size_t)W.wsc[wl] * per + (q - wl * per)];
+    }
+    if ((int)threadIdx.x < wpw) W.wnob[threadIdx.x] = (int)threadIdx.x < worlds_valid ? D.sc_nobst[W.wsc[threadIdx.x]] : 0;
 }
 
 __device__ __forceinline__ void lds3_store_moved(const Lds3& W, const Agent& A, int lane) {
@@ -294,15 +309,14 @@ __device__ __forceinline__ void ego_lp_inputs3(const CagymDev& D, const Lds3& W,
     publish_pref_velocity3(W, a);
     if (!OBST) return;
     int no = 0;
-    if (W.trvo[a]) {
+    if (ko > 0 && W.trvo[a]) {
         const int wl = (int)__umulhi((uint32_t)a, inv_m);
-        const int sidx = W.wsc[wl];
-        const int n_obst = D.sc_nobst[sidx];
+        const int n_obst = W.wnob[wl];
         if (n_obst > 0) {
             const float px = (float)W.tpx[a], py = (float)W.tpy[a], vx = (float)W.tvx[a], vy = (float)W.tvy[a];
             const float radius = (float)((1 + 15e-2) * W.tr[a]), max_speed = W.lpr[a];
             float2* nbr = reinterpret_cast<float2*>(W.lp3) + a;  // private column of the (idle) linearProgram3 scratch
-            no = orca_obstacle_lines(D.sc_obst + (size_t)sidx * D.Kobs * 4, n_obst, px, py, vx, vy, radius, max_speed, 5.0f,
+            no = orca_obstacle_lines(W.rect + wl * D.Kobs * 4, n_obst, px, py, vx, vy, radius, max_speed, 5.0f,
                                      W.sorted + a, AS, ko, nbr, AS);
             const float2 s0 = W.lpc[a];
             bool viol = false;
@@ -511,7 +525,7 @@ __device__ __forceinline__ void laser_beam3(const CagymDev& D, const Lds3& W, fl
     if (slot < W.wn[wl]) {
         const int sidx = W.wsc[wl];
         const uint32_t* map = (D.map_bits && D.sc_nobst[sidx] > 0) ? D.map_bits + (size_t)sidx * CAGYM_MAPD * CAGYM_MAPW : nullptr;
-        v = laserscan_beam(map, W.tpx[a], W.tpy[a], W.th[a], W.tr[a], b);
+        v = laserscan_beam(map, W.tpx[a], W.tpy[a], W.th[a], W.tr[a], b);  // (the count is an L2 hit; the raster gathers dominate)
     }
     laser_out[((size_t)world * M + slot) * 16 + b] = v;
 }
@@ -519,11 +533,12 @@ __device__ __forceinline__ void laser_beam3(const CagymDev& D, const Lds3& W, fl
 // claim-and-process loop of the observation workers: chunks 0 .. nck-1 are 64 directed pairs each, chunk nck is the
 // scalar-observation store of the agent slots, chunks nck+1 .. are 4 agents x 16 laser beams each (when asked for).  Every wave of the workgroup may call it; a wave leaves when the
 // counter has run past the last chunk (every wave reaches that: the counter only grows).
+template <bool OBST>
 __device__ __forceinline__ void observation_chunks3(const CagymDev& D, const Lds3& W, const CagymOut& o, int npairs, int M, int MP,
                                                     int K, int wpw, int worlds_valid, uint32_t inv_m) {
     const int lane = threadIdx.x & (CAGYM_WAVE - 1);
     const int nck = (npairs + CAGYM_WAVE - 1) / CAGYM_WAVE;
-    const int nlaser = o.laserscan ? (wpw * M + 3) / 4 : 0;
+    const int nlaser = (OBST && o.laserscan) ? (wpw * M + 3) / 4 : 0;
     for (;;) {
         int c = 0;
         if (lane == 0) c = __hip_atomic_fetch_add(&W.flag[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -533,7 +548,7 @@ __device__ __forceinline__ void observation_chunks3(const CagymDev& D, const Lds
             if (o.obs_oas) oas_row3(W, o.obs_oas, c * CAGYM_WAVE + lane, npairs, M, MP, K, wpw, worlds_valid, inv_m);
         } else if (c == nck) {
             ego_obs3(D, W, o.obs_ego, lane, M, wpw, inv_m);
-        } else {
+        } else if (OBST) {
             laser_beam3(D, W, o.laserscan, (c - nck - 1) * 4 + (lane >> 4), lane & 15, M, wpw, inv_m);
         }
     }
@@ -551,7 +566,9 @@ __device__ __forceinline__ CagymOut out_slice3(const CagymOut& out, int t, size_
 }
 
 // n_steps env.step() calls of the workgroup's worlds.  ext: external actions of the (single) step or null.
-// OBST: the handle has rectangles and RVO agents (obstacle half-planes, LP groups with 4 half-planes per lane).
+// OBST: the handle's worlds may hold rectangles (max_obstacles > 0): wall test, LaserScan, and - when RVO agents live among
+// them (D.ko > 0) - obstacle half-planes with LP groups of 4 half-planes per lane.  The free-space instantiation carries
+// none of that code (it cost the headline kernel 7 VGPRs and a spill).
 template <int NT, int MT, int WPWT, bool AUTO_RESET, bool OBST>
 __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const float* ext, const CagymOut& out, int n_steps,
                                   bool any_rvo) {
@@ -560,7 +577,7 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
     constexpr bool TWO = !(MT > 0 && MT - 1 <= GW + 1);  // more than GW + 1 half-planes possible: two per lane of an LP group
     const int M = MT ? MT : D.M, K = M - 1, MP = cagym_mp(M);
     const int AS = cagym_as(M, WPWT);
-    const int ko = OBST ? 2 * D.Kobs : 0;  // an agent outside a rectangle sees at most 2 of its edges from their right side
+    const int ko = OBST ? D.ko : 0;  // 2 * Kobs: an agent outside a rectangle sees at most 2 of its edges from their right side
     constexpr int LPL = OBST ? 4 : 2;
     const Lds3 W = carve_lds3(smem, M, AS, NT, ko, LPL);
     LaneCtx C = make_ctx2(D, M, WPWT ? WPWT : CAGYM_WAVE / M);
@@ -605,6 +622,10 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
         }
         if (tid < 8) W.flag[tid] = 0;
         __syncthreads();
+        if (OBST && ko > 0) {
+            stage_rects3(D, W, C.wpw, C.worlds_valid);
+            __syncthreads();
+        }
         if (agent_lane && any_rvo) ego_lp_inputs3<OBST>(D, W, tid, M, AS, ko, inv_m);
         else if (agent_lane) publish_pref_velocity3(W, tid);
         if (any_rvo) {
@@ -750,7 +771,7 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
 #ifndef CAGYM_NO_LAG_PRIORITY
             __builtin_amdgcn_s_setprio(0);
 #endif
-            observation_chunks3(D, W, o_prev, npairs, M, MP, K, C.wpw, C.worlds_valid, inv_m);
+            observation_chunks3<OBST>(D, W, o_prev, npairs, M, MP, K, C.wpw, C.worlds_valid, inv_m);
 #ifndef CAGYM_NO_LAG_PRIORITY
             if (lagging) __builtin_amdgcn_s_setprio(3);
             else __builtin_amdgcn_s_setprio(1);
@@ -774,7 +795,7 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
         //      the next step's LP inputs (Dynamics.update_ego_frame waits for phase B: nothing before the rows needs it) -------
         if (tid >= NT - CAGYM_WAVE) {
             const int a = tid - (NT - CAGYM_WAVE);
-            if (a < nagents && any_rvo) ego_lp_inputs3<OBST>(D, W, a, M, AS, ko, inv_m);
+            if (a < nagents && any_rvo && t + 1 < n_steps) ego_lp_inputs3<OBST>(D, W, a, M, AS, ko, inv_m);
             WAVETRACE(t, 7);
         }
         for (int p = tid; p < nup; p += NT) pair_distances3<MT>(D, W, p, M, MP);
@@ -804,7 +825,7 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
                         dmin = fmin(dmin, fmin(fmin(g0.x, g0.y), fmin(g1.x, g1.y)));
                     }
                     const bool coll_agent = hits != 0;
-                    if (D.map_bits) {
+                    if (OBST && D.map_bits) {
                         int sidx = (int)(((long long)C.world + (long long)C.episode * D.N) % D.S);
                         if (D.sc_nobst[sidx] > 0)
                             coll_wall = wall_collision(D.map_bits + (size_t)sidx * CAGYM_MAPD * CAGYM_MAPW, S.px, S.py, S.r);
@@ -891,12 +912,16 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
         WAVETRACE(t, 11);
         // ---- rare: a world restarted on its next scenario -> everything derived from the old episode is rebuilt -------------
         if (AUTO_RESET && W.flag[0]) {
+            if (OBST && ko > 0 && more) {  // the restarted worlds' rectangles
+                stage_rects3(D, W, C.wpw, C.worlds_valid);
+                __syncthreads();
+            }
             if (tid >= NT - CAGYM_WAVE) {
                 const int a = tid - (NT - CAGYM_WAVE);
                 if (a < nagents) {
                     const int wl = (int)__umulhi((uint32_t)a, inv_m);
                     W.trvo[a] = live_rvo(W.tst[a], (a - wl * M) < W.wn[wl]);
-                    if (any_rvo) ego_lp_inputs3<OBST>(D, W, a, M, AS, ko, inv_m);
+                    if (any_rvo && more) ego_lp_inputs3<OBST>(D, W, a, M, AS, ko, inv_m);
                 }
             }
             for (int p = tid; p < nup; p += NT) pair_distances3<MT>(D, W, p, M, MP);
@@ -912,7 +937,7 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
     // ---- epilogue: observation of the last step on every wave, agent records -> HBM ------------------------------------------
     {
         const CagymOut o_last = out_slice3(out, n_steps - 1, (size_t)D.N, NM, M);
-        observation_chunks3(D, W, o_last, npairs, M, MP, K, C.wpw, C.worlds_valid, inv_m);
+        observation_chunks3<OBST>(D, W, o_last, npairs, M, MP, K, C.wpw, C.worlds_valid, inv_m);
         if (C.valid) {
             const Agent A = lds3_load_agent(W, threadIdx.x);  // own lane's record, written by this lane
             store_agent(D, A, (size_t)C.world * M + C.slot, true);
@@ -937,7 +962,9 @@ __global__ void __launch_bounds__(NT, OBST ? 2 : cagym_min_waves3(NT, MT)) k_rol
 #ifdef CAGYM_WGTRACE
     if (threadIdx.x == 0 && blockIdx.x < CAGYM_WGTRACE_MAXWG) g_wgtrace[blockIdx.x * CAGYM_WGTRACE_W + 39] = 0;
 #endif
-    run_steps3<NT, MT, WPWT, AUTO_RESET, OBST>(D, smem, nullptr, out, n_steps, any_rvo != 0);
+    // the OBST body is too large for the inliner's taste; called out of line it would get the device struct through scratch
+    if (OBST) { [[clang::always_inline]] run_steps3<NT, MT, WPWT, AUTO_RESET, OBST>(D, smem, nullptr, out, n_steps, any_rvo != 0); }
+    else run_steps3<NT, MT, WPWT, AUTO_RESET, OBST>(D, smem, nullptr, out, n_steps, any_rvo != 0);
 #ifdef CAGYM_WGTRACE
     WGTRACE(38);
     if (threadIdx.x == 0 && blockIdx.x < CAGYM_WGTRACE_MAXWG)
@@ -949,5 +976,6 @@ __global__ void __launch_bounds__(NT, OBST ? 2 : cagym_min_waves3(NT, MT)) k_rol
 template <int NT, int MT, int WPWT, bool AUTO_RESET, bool OBST>
 __global__ void __launch_bounds__(NT, OBST ? 2 : cagym_min_waves3(NT, MT)) k_step3(CagymDev D, const float* ext, CagymOut out, int any_rvo) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    run_steps3<NT, MT, WPWT, AUTO_RESET, OBST>(D, smem, ext, out, 1, any_rvo != 0);
+    if (OBST) { [[clang::always_inline]] run_steps3<NT, MT, WPWT, AUTO_RESET, OBST>(D, smem, ext, out, 1, any_rvo != 0); }
+    else run_steps3<NT, MT, WPWT, AUTO_RESET, OBST>(D, smem, ext, out, 1, any_rvo != 0);
 }

@@ -506,19 +506,19 @@ struct OrcaVertex {
     bool convex;
 };
 
-// counter-clockwise polygon [(xu,yu), (xl,yu), (xl,yl), (xu,yl)] of test_cases.py:2496; vertex k of rect = xl, yl, xu, yu
-__device__ __forceinline__ OrcaVertex orca_rect_vertex(const double* rect, int k) {
-    const float xl = (float)rect[0], yl = (float)rect[1], xu = (float)rect[2], yu = (float)rect[3];
-    const int nx = (k + 1) & 3, pv = (k + 3) & 3;
-    const float X = (k == 0 || k == 3) ? xu : xl, Y = (k < 2) ? yu : yl;
-    const float Xn = (nx == 0 || nx == 3) ? xu : xl, Yn = (nx < 2) ? yu : yl;
-    const float Xp = (pv == 0 || pv == 3) ? xu : xl, Yp = (pv < 2) ? yu : yl;
+// counter-clockwise polygon [(xu,yu), (xl,yu), (xl,yl), (xu,yl)] of test_cases.py:2496.  RVOSimulator::addObstacle's unit
+// directions (normalize = v * (1 / |v|): not always exactly +-1) and convexity flags are computed once per scenario pool by
+// cagym_set_scenarios with the same fp32 expressions and kept beside the rectangle: prep[0] = (xl, yl, xu, yu) as float,
+// prep[1] = (u0.x, u0.y, u1.x, u1.y), prep[2] = (u2.x, u2.y, u3.x, u3.y), prep[3].x = convex bits.
+__device__ __forceinline__ OrcaVertex orca_rect_vertex(const float4* prep, int k) {
+    const float4 r = prep[0];
+    const float4 u = prep[1 + (k >> 1)];
     OrcaVertex V;
-    const float ex = Xn - X, ey = Yn - Y;
-    const float inv = 1.0f / sqrtf(ex * ex + ey * ey);
-    V.x = X; V.y = Y;
-    V.ux = ex * inv; V.uy = ey * inv;
-    V.convex = detf(Xp - Xn, Yp - Yn, X - Xp, Y - Yp) >= 0.0f;  // leftOf(prev, this, next) >= 0
+    V.x = (k == 0 || k == 3) ? r.z : r.x;
+    V.y = (k < 2) ? r.w : r.y;
+    V.ux = (k & 1) ? u.z : u.x;
+    V.uy = (k & 1) ? u.w : u.y;
+    V.convex = (__float_as_uint(prep[3].x) >> k) & 1u;
     return V;
 }
 
@@ -649,7 +649,7 @@ __device__ inline bool orca_obstacle_line(const OrcaVertex& o1, const OrcaVertex
 // Obstacle neighbours (nearest first) of one ego and their ORCA lines, written to L[k * stride], k < return value <= cap.
 // nbr: private scratch of the lane, `cap` entries (key = squared distance, id = 4 * rectangle + edge) at nbr_stride.
 // One lane per ego; every loop is bounded by 4 * n_obst.
-__device__ inline int orca_obstacle_lines(const double* rects, int n_obst, float px, float py, float vx, float vy, float radius,
+__device__ inline int orca_obstacle_lines(const float4* rects, int n_obst, float px, float py, float vx, float vy, float radius,
                                           float max_speed, float time_horizon_obst, float4* L, int stride, int cap,
                                           float2* nbr, int nbr_stride) {
     const float range = time_horizon_obst * max_speed + radius, range_sq = range * range;
@@ -658,6 +658,7 @@ __device__ inline int orca_obstacle_lines(const double* rects, int n_obst, float
         for (int k = 0; k < 4; k++) {
             const OrcaVertex o1 = orca_rect_vertex(rects + 4 * r, k), o2 = orca_rect_vertex(rects + 4 * r, (k + 1) & 3);
             const float left = detf(o1.x - px, o1.y - py, o2.x - o1.x, o2.y - o1.y);  // leftOf(o1, o2, position)
+            if (!(left < 0.0f)) continue;  // only from its right side (the agent can see it); half of the edges end here
             const float ex = o2.x - o1.x, ey = o2.y - o1.y;
             const float dsq_line = (left * left) / (ex * ex + ey * ey);
             if (!(dsq_line < range_sq) || !(left < 0.0f)) continue;  // only from its right side (the agent can see it)
