@@ -301,33 +301,108 @@ __device__ __forceinline__ void publish_pref_velocity3(const Lds3& W, int a) {
     W.busy[a] = 0;
 }
 
-// Everything of the next ORCA solve that depends on ego a alone: preferred velocity / LP start and, in worlds with
-// rectangles, the obstacle half-planes (one lane per ego; RVOPolicy.py:56-57, Agent::computeNewVelocity's first half).
-// The obstacle lines go to rows 0 .. nobl-1 of the ego's column; the busy test covers them like the agent lines.
+// Obstacle half-planes of every live RVO ego of the workgroup (RVOPolicy.py:56-57; the obstacle half of
+// Agent::computeNewVelocity), on all lanes in four sub-steps: (1) one lane per (ego, rectangle) tests the four edges and
+// appends the neighbours to the ego's candidate list (LDS counter); (2) one lane per ego sorts its candidates by (squared
+// distance, rectangle, edge) - the order Agent::insertObstacleNeighbor's insertion sort produces; (3) one lane per (ego,
+// candidate) builds the candidate's half-plane (it does not depend on the earlier ones); (4) one lane per ego walks its
+// candidates in order, drops those already covered by a kept line, compacts the kept lines to rows 0 .. nobl-1 of its column
+// and tests them against the LP start.  Needs: W.rect staged, W.lpc published, W.nobl zero, a barrier behind all three; every
+// thread of the workgroup calls it (three barriers inside); the caller's next barrier publishes the result.
+__device__ inline void obstacle_lines_phase3(const CagymDev& D, const Lds3& W, int M, int AS, int ko, int nagents, uint32_t inv_m) {
+    const int tid = threadIdx.x, NTT = blockDim.x, Kobs = D.Kobs;
+    float2* nbr = reinterpret_cast<float2*>(W.lp3);  // [ko][AS] candidates (squared distance, id) in the idle LP3 scratch
+    int* todo = reinterpret_cast<int*>(nbr + ko * AS);  // [<= nagents * ko] (ego << 8 | candidate) behind them
+    const float inv_tho = 1.0f / 5.0f;
+    if (tid == 0) W.flag[5] = 0;  // the barrier behind sub-step 1 publishes it
+    for (int q = tid; q < nagents * Kobs; q += NTT) {
+        const int a = q / Kobs, r = q - a * Kobs;
+        if (!W.trvo[a]) continue;
+        const int wl = (int)__umulhi((uint32_t)a, inv_m);
+        if (r >= W.wnob[wl]) continue;
+        const float px = (float)W.tpx[a], py = (float)W.tpy[a];
+        const float radius = (float)((1 + 15e-2) * W.tr[a]), max_speed = (float)W.tpref[a];
+        const float range = 5.0f * max_speed + radius, range_sq = range * range;
+        const float4* rect = W.rect + (wl * Kobs + r) * 4;
+        for (int k = 0; k < 4; k++) {
+            float dsq;
+            if (orca_edge_is_neighbour(rect, k, px, py, range_sq, dsq)) {
+                const int slot = __hip_atomic_fetch_add(&W.nobl[a], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (slot < ko) nbr[slot * AS + a] = make_float2(dsq, __int_as_float(4 * r + k));
+            }
+        }
+    }
+    __syncthreads();
+    if (tid >= NTT - CAGYM_WAVE) {
+        const int a = tid - (NTT - CAGYM_WAVE);
+        if (a < nagents) {
+            int n = W.nobl[a];
+            n = n < ko ? n : ko;
+            for (int i = 1; i < n; i++) {  // insertion sort by (squared distance, id): n <= 2 per rectangle in range
+                const float2 c = nbr[i * AS + a];
+                int j = i;
+                while (j > 0) {
+                    const float2 p = nbr[(j - 1) * AS + a];
+                    if (!(c.x < p.x || (c.x == p.x && __float_as_int(c.y) < __float_as_int(p.y)))) break;
+                    nbr[j * AS + a] = p;
+                    j--;
+                }
+                nbr[j * AS + a] = c;
+            }
+            W.nobl[a] = n;
+            // the (ego, candidate) pairs of the whole workgroup as one dense list: sub-step 3 is one round of lanes
+            const int base = n > 0 ? __hip_atomic_fetch_add(&W.flag[5], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0;
+            for (int i = 0; i < n; i++) todo[base + i] = (a << 8) | i;
+        }
+    }
+    __syncthreads();
+    const int ntodo = W.flag[5];
+    for (int q = tid; q < ntodo; q += NTT) {
+        const int a = todo[q] >> 8, i = todo[q] & 255;
+        const int wl = (int)__umulhi((uint32_t)a, inv_m);
+        const float px = (float)W.tpx[a], py = (float)W.tpy[a], vx = (float)W.tvx[a], vy = (float)W.tvy[a];
+        const float radius = (float)((1 + 15e-2) * W.tr[a]);
+        float4 ln;
+        const bool ok = orca_obstacle_line_of(W.rect + wl * Kobs * 4, __float_as_int(nbr[i * AS + a].y), px, py, vx, vy, radius, inv_tho, ln);
+        if (!ok) ln.z = __int_as_float(0x7fc00000);  // "this edge contributes no half-plane": NaN direction
+        W.sorted[i * AS + a] = ln;
+    }
+    __syncthreads();
+    if (tid >= NTT - CAGYM_WAVE) {
+        const int a = tid - (NTT - CAGYM_WAVE);
+        if (a < nagents) {
+            const int n = W.nobl[a];
+            int nl = 0;
+            if (n > 0) {
+                const int wl = (int)__umulhi((uint32_t)a, inv_m);
+                const float px = (float)W.tpx[a], py = (float)W.tpy[a];
+                const float radius = (float)((1 + 15e-2) * W.tr[a]);
+                const float2 s0 = W.lpc[a];
+                bool viol = false;
+                for (int i = 0; i < n; i++) {
+                    const int id = __float_as_int(nbr[i * AS + a].y);
+                    bool covered = false;
+                    for (int j = 0; j < nl; j++) covered |= orca_edge_covered_by(W.rect + wl * Kobs * 4, id, px, py, radius, inv_tho, W.sorted[j * AS + a]);
+                    if (covered) continue;
+                    const float4 ln = W.sorted[i * AS + a];
+                    if (ln.z != ln.z) continue;  // no half-plane from this edge
+                    W.sorted[nl * AS + a] = ln;   // nl <= i: in place
+                    nl++;
+                    viol |= detf(ln.z, ln.w, ln.x - s0.x, ln.y - s0.y) > 0.0f;
+                }
+                if (viol) W.busy[a] = 1;
+            }
+            W.nobl[a] = nl;
+        }
+    }
+}  // (W.flag[5] is read before the third barrier and reset behind the caller's barrier at the next call)
+
+// What of the next ORCA solve depends on ego a alone: preferred velocity / LP start (the obstacle half-planes of worlds with
+// rectangles follow in obstacle_lines_phase3, which counts on nobl = 0).
 template <bool OBST>
 __device__ __forceinline__ void ego_lp_inputs3(const CagymDev& D, const Lds3& W, int a, int M, int AS, int ko, uint32_t inv_m) {
     publish_pref_velocity3(W, a);
-    if (!OBST) return;
-    int no = 0;
-    if (ko > 0 && W.trvo[a]) {
-        const int wl = (int)__umulhi((uint32_t)a, inv_m);
-        const int n_obst = W.wnob[wl];
-        if (n_obst > 0) {
-            const float px = (float)W.tpx[a], py = (float)W.tpy[a], vx = (float)W.tvx[a], vy = (float)W.tvy[a];
-            const float radius = (float)((1 + 15e-2) * W.tr[a]), max_speed = W.lpr[a];
-            float2* nbr = reinterpret_cast<float2*>(W.lp3) + a;  // private column of the (idle) linearProgram3 scratch
-            no = orca_obstacle_lines(W.rect + wl * D.Kobs * 4, n_obst, px, py, vx, vy, radius, max_speed, 5.0f,
-                                     W.sorted + a, AS, ko, nbr, AS);
-            const float2 s0 = W.lpc[a];
-            bool viol = false;
-            for (int k = 0; k < no; k++) {
-                const float4 ln = W.sorted[k * AS + a];
-                viol |= detf(ln.z, ln.w, ln.x - s0.x, ln.y - s0.y) > 0.0f;
-            }
-            if (viol) W.busy[a] = 1;
-        }
-    }
-    W.nobl[a] = no;
+    if (OBST) W.nobl[a] = 0;
 }
 
 // unordered pair p of the workgroup -> (world of the workgroup, i, j); compile-time M or run-time M (magic division)
@@ -628,6 +703,10 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
         }
         if (agent_lane && any_rvo) ego_lp_inputs3<OBST>(D, W, tid, M, AS, ko, inv_m);
         else if (agent_lane) publish_pref_velocity3(W, tid);
+        if (OBST && ko > 0 && any_rvo) {
+            __syncthreads();
+            obstacle_lines_phase3(D, W, M, AS, ko, nagents, inv_m);
+        }
         if (any_rvo) {
             for (int p = tid; p < nup; p += NT) pair_distances3<MT>(D, W, p, M, MP);
             __syncthreads();
@@ -800,6 +879,10 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
         }
         for (int p = tid; p < nup; p += NT) pair_distances3<MT>(D, W, p, M, MP);
         WAVETRACE(t, 8);
+        if (OBST && ko > 0 && any_rvo && t + 1 < n_steps) {
+            __syncthreads();
+            obstacle_lines_phase3(D, W, M, AS, ko, nagents, inv_m);
+        }
         __syncthreads();
         STAMP(5);
         WAVETRACE(t, 9);
@@ -925,6 +1008,10 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
                 }
             }
             for (int p = tid; p < nup; p += NT) pair_distances3<MT>(D, W, p, M, MP);
+            if (OBST && ko > 0 && any_rvo && more) {
+                __syncthreads();
+                obstacle_lines_phase3(D, W, M, AS, ko, nagents, inv_m);
+            }
             __syncthreads();
             if (any_rvo && more)
                 for (int p = tid; p < nup; p += NT) half_planes3<MT>(D, W, p, M, MP, AS, ko);

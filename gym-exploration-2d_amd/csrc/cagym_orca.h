@@ -646,6 +646,39 @@ __device__ inline bool orca_obstacle_line(const OrcaVertex& o1, const OrcaVertex
     return true;
 }
 
+// Is edge k of the prepared rectangle an obstacle neighbour of the agent (Agent::computeNeighbors: seen from its right side,
+// closer than the range)?  Returns its squared distance through dsq.
+__device__ __forceinline__ bool orca_edge_is_neighbour(const float4* rect, int k, float px, float py, float range_sq, float& dsq) {
+    const OrcaVertex o1 = orca_rect_vertex(rect, k), o2 = orca_rect_vertex(rect, (k + 1) & 3);
+    const float left = detf(o1.x - px, o1.y - py, o2.x - o1.x, o2.y - o1.y);  // leftOf(o1, o2, position)
+    if (!(left < 0.0f)) return false;
+    const float ex = o2.x - o1.x, ey = o2.y - o1.y;
+    const float dsq_line = (left * left) / (ex * ex + ey * ey);
+    if (!(dsq_line < range_sq)) return false;
+    dsq = orca_dist_sq_point_segment(o1.x, o1.y, o2.x, o2.y, px, py);
+    return dsq < range_sq;
+}
+
+// The half-plane of obstacle edge `id` (= 4 * rectangle + edge) WITHOUT the already-covered test (nl = 0): the line does
+// not depend on the lines built before it, so all of an ego's candidate lines can be built side by side.
+__device__ __forceinline__ bool orca_obstacle_line_of(const float4* rects, int id, float px, float py, float vx, float vy,
+                                                      float radius, float inv_tho, float4& out) {
+    const int r = id >> 2, k = id & 3;
+    const OrcaVertex o1 = orca_rect_vertex(rects + 4 * r, k), o2 = orca_rect_vertex(rects + 4 * r, (k + 1) & 3),
+                     pv = orca_rect_vertex(rects + 4 * r, (k + 3) & 3);
+    return orca_obstacle_line(o1, o2, pv, px, py, vx, vy, radius, inv_tho, nullptr, 0, 0, out);
+}
+
+// Agent::computeNewVelocity's "already covered" test of edge `id` against one earlier obstacle line
+__device__ __forceinline__ bool orca_edge_covered_by(const float4* rects, int id, float px, float py, float radius, float inv_tho,
+                                                     const float4 lj) {
+    const int r = id >> 2, k = id & 3;
+    const OrcaVertex o1 = orca_rect_vertex(rects + 4 * r, k), o2 = orca_rect_vertex(rects + 4 * r, (k + 1) & 3);
+    const float rp1x = o1.x - px, rp1y = o1.y - py, rp2x = o2.x - px, rp2y = o2.y - py;
+    return detf(inv_tho * rp1x - lj.x, inv_tho * rp1y - lj.y, lj.z, lj.w) - inv_tho * radius >= -RVO_EPS &&
+           detf(inv_tho * rp2x - lj.x, inv_tho * rp2y - lj.y, lj.z, lj.w) - inv_tho * radius >= -RVO_EPS;
+}
+
 // Obstacle neighbours (nearest first) of one ego and their ORCA lines, written to L[k * stride], k < return value <= cap.
 // nbr: private scratch of the lane, `cap` entries (key = squared distance, id = 4 * rectangle + edge) at nbr_stride.
 // One lane per ego; every loop is bounded by 4 * n_obst.
