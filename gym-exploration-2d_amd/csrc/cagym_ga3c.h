@@ -183,3 +183,259 @@ __global__ void __launch_bounds__(256) k_ga3c_forward(const float* __restrict__ 
         }
     }
 }
+
+
+// ---- the same forward pass on the matrix cores (round 2) ------------------------------------------------------------------
+// v_mfma_f32_32x32x2_f32: exact fp32 products and sums, k in order - the fmaf chain the kernel above evaluates lane by lane, at
+// the same peak rate (measured 147 TFLOP/s, tools/micro/mfma_rate.hip) but with ONE register operand per 32 x 32 x 2 block
+// instead of a broadcast LDS read per 4 FMAs.  One workgroup = 32 agents (the M side of the tile); wave w owns 64 output
+// neurons = two 32 x 32 accumulator tiles (2 x 16 VGPRs).  A operand: the layer input in LDS as [k][agent] (lane l reads row
+// k0 + (l >> 5), agent l & 31: conflict-free ds_read_b32); B operand: weight W[k0 + (l >> 5)][column(l & 31)].
+//   LSTM: the wave's 72 x 64 weight block is loaded ONCE into 72 VGPRs and reused by all (<= 10) steps; the columns are dealt
+//   so that a wave holds all four gates of its 16 units (tile 0: i | j, tile 1: f | o): the cell update needs one
+//   v_permlane16_swap per accumulator pair, the cell state of a (unit, agent) lives in a register for the whole sequence, h is
+//   double-buffered in LDS (one barrier per step), the 10 x 7 sequence features are fetched once.
+//   Dense layers: weights stream from L2 through a hand-pipelined loop (below).
+// Layouts (MI355X guide): A[i = l & 31][k = l >> 5], B[k = l >> 5][j = l & 31], D reg r of lane l = row (r & 3) + 8 (r >> 2) +
+// 4 (l >> 5), column l & 31.
+typedef float ga_f32x16 __attribute__((ext_vector_type(16)));
+
+// One dense layer's accumulation for this wave's two tiles: acc += in[32 agents x K] * Wt[K x columns c0 / c1].  The weights come
+// from L2 (every workgroup reads the same 0.7 MB), so the loop is software-pipelined by hand over two named register sets
+// (no copies: the compiler would coalesce them and serialise load -> use): while the 2 U matrix instructions of one block
+// issue (U = 8: 1024 matrix-core cycles), the U k-pairs of the next block are in flight.  Loads are unconditional (row index
+// clamped, the A operand zeroed beyond K), so the loop body has no branches.  TILES = 1: only c0 / acc0.
+template <int U, int TILES>
+struct GaOperands {
+    float a[U], b0[U], b1[U];
+};
+template <int U, int TILES>
+__device__ __forceinline__ void ga_fetch(GaOperands<U, TILES>& o, const float* __restrict__ in, int K, const float* __restrict__ Wt, int ldw,
+                                         int c0, int c1, int blk) {
+    const int lane = threadIdx.x & 63, half = lane >> 5, j = lane & 31;
+#pragma unroll
+    for (int i = 0; i < U; i++) {
+        const int k = 2 * (blk * U + i) + half;
+        const int kc = k < K ? k : K - 1;
+        const float av = in[kc * 32 + j];
+        o.a[i] = k < K ? av : 0.f;
+        o.b0[i] = Wt[(size_t)kc * ldw + c0];
+        if (TILES == 2) o.b1[i] = Wt[(size_t)kc * ldw + c1];
+    }
+}
+template <int U, int TILES>
+__device__ __forceinline__ void ga_issue(const GaOperands<U, TILES>& o, bool use0, ga_f32x16& acc0, ga_f32x16& acc1) {
+#pragma unroll
+    for (int i = 0; i < U; i++) {
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a[i], TILES == 2 ? o.b0[i] : (use0 ? o.b0[i] : 0.f), acc0, 0, 0, 0);
+        if (TILES == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a[i], o.b1[i], acc1, 0, 0, 0);
+    }
+}
+template <int U, int TILES>
+__device__ __forceinline__ void ga_mfma_layer(const float* __restrict__ in, int K, const float* __restrict__ Wt, int ldw, int c0, int c1,
+                                              bool use0, ga_f32x16& acc0, ga_f32x16& acc1) {
+    const int kp = (K + 1) >> 1, nblk = (kp + U - 1) / U;
+    GaOperands<U, TILES> A, Bq;
+    ga_fetch<U, TILES>(A, in, K, Wt, ldw, c0, c1, 0);
+#pragma unroll 1
+    for (int blk = 0; blk < nblk; blk += 2) {  // straight-line body: blocks past the end fetch clamped rows with a zero A operand
+        // sched_barrier: the machine scheduler would otherwise sink each load to just before its use
+        ga_fetch<U, TILES>(Bq, in, K, Wt, ldw, c0, c1, blk + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        ga_issue<U, TILES>(A, use0, acc0, acc1);
+        __builtin_amdgcn_sched_barrier(0);
+        ga_fetch<U, TILES>(A, in, K, Wt, ldw, c0, c1, blk + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        ga_issue<U, TILES>(Bq, use0, acc0, acc1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// gate non-linearities on the transcendental unit (v_exp_f32 / v_rcp_f32, ~1 ulp each): the cell update of 2048 (unit, agent) cells
+// per step would otherwise cost more issue cycles than the step's 72 matrix instructions.  TensorFlow's own fp32 kernels are
+// rational approximations of the same accuracy class; the network is "parity unpinned"  and checked to 1e-4 on probabilities.
+__device__ __forceinline__ float ga_fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * x)); }
+__device__ __forceinline__ float ga_fast_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008f * x)); }
+
+__device__ __forceinline__ ga_f32x16 ga_splat(float v) {
+    ga_f32x16 r;
+#pragma unroll
+    for (int i = 0; i < 16; i++) r[i] = v;
+    return r;
+}
+
+// store one accumulator tile (ReLU applied) as rows [neuron][agent] of the activation buffer: reg r <-> agent (r & 3) +
+// 8 (r >> 2) + 4 half, four consecutive agents per 16-byte store
+__device__ __forceinline__ void ga_store_tile_relu(float* act, int neuron, const ga_f32x16& acc) {
+    const int half = (threadIdx.x & 63) >> 5;
+    float4* row = reinterpret_cast<float4*>(act + neuron * 32);
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        row[2 * q + half] = make_float4(fmaxf(acc[4 * q], 0.f), fmaxf(acc[4 * q + 1], 0.f), fmaxf(acc[4 * q + 2], 0.f), fmaxf(acc[4 * q + 3], 0.f));
+}
+
+// 200 VGPRs (72 of them the LSTM weights) -> 2 workgroups per CU; forcing 3 spills weights and measures the same
+__global__ void __launch_bounds__(256, 2) k_ga3c_forward_mfma(const float* __restrict__ Wb, const float* __restrict__ state,
+                                                           const int32_t* __restrict__ agent_idx, int B,
+                                                           const double* __restrict__ pref, float* ext_actions,
+                                                           int32_t* action_index, float* probs) {
+    constexpr int AG = 32, HB = (4 + GA_H + 1) * AG;
+    // One 40.6 KB LDS block (3 workgroups per CU):
+    //   hb0 | hb1: [4 host features | 64 hidden | one zero row][agent], double-buffered over the LSTM steps (one barrier per step);
+    //              the sequence starts in buffer tmax & 1 so that it always ends in hb0, which is layer1's input as it stands;
+    //   xs:        the normalised features of all 10 sequence slots, fetched once;
+    //   za:        layer activations [neuron][agent], over hb1 and xs (both dead when layer1 writes its output);
+    //   part, logit: over hb0 (dead once layer1 has been read).
+    __shared__ __attribute__((aligned(16))) float lds[HB + GA_W * AG];
+    __shared__ int nseq[AG];
+    float* hb = lds;
+    float* xs = lds + 2 * HB;
+    float* za = lds + HB;
+    float* part = lds;                 // logits: partial sums of the four waves [4][AG][12]
+    float* logit = lds + 4 * AG * 12;  // [AG][12]
+    static_assert(2 * HB + 10 * 7 * AG <= HB + GA_W * AG && 5 * AG * 12 <= HB, "LDS aliasing");
+    const int n = threadIdx.x, tile = blockIdx.x * AG;
+    const int lane = n & 63, wave = n >> 6, half = lane >> 5, j = lane & 31;
+    for (int e = n; e < AG * 5; e += 256) {
+        const int g = e / 5, f = e - g * 5;
+        const int a = tile + g < B ? agent_idx[tile + g] : -1;
+        const float x = a >= 0 ? state[(size_t)a * 76 + 1 + f] : 0.f;
+        if (f == 0) {
+            int ns = (int)x;
+            nseq[g] = a >= 0 ? (ns < 0 ? 0 : (ns > 10 ? 10 : ns)) : 0;
+        } else {
+            const float avg = f == 3 ? 1.0f : (f == 4 ? 0.5f : 0.0f);
+            const float sd = f == 1 ? 5.0f : (f == 2 ? 3.14f : 1.0f);
+            hb[(f - 1) * AG + g] = hb[HB + (f - 1) * AG + g] = (x - avg) / sd;
+        }
+    }
+    for (int e = n; e < 10 * 7 * AG; e += 256) {
+        const int tc = e / AG, g = e - tc * AG, c = tc % 7;
+        const int a = tile + g < B ? agent_idx[tile + g] : -1;
+        const float x = a >= 0 ? state[(size_t)a * 76 + 6 + tc] : 0.f;
+        const float avg = c == 4 ? 0.5f : (c == 6 ? 1.0f : 0.0f);
+        const float sd = (c == 0 || c == 1 || c == 5) ? 5.0f : 1.0f;
+        xs[e] = (x - avg) / sd;
+    }
+    for (int e = n; e < 65 * AG; e += 256) hb[4 * AG + e] = hb[HB + 4 * AG + e] = 0.f;  // h = 0 and the padding rows
+    // ---- LSTM: this lane's (unit, agent) cells: unit = 16 wave + (j & 15), agents = regs 8 (j >> 4) .. + 7 of its half ----
+    const int unit = 16 * wave + (j & 15);
+    const int rbase = 8 * (j >> 4);  // lanes j < 16 finish regs 0..7, their partners (j >= 16) regs 8..15
+    float cst[8];  // cell states; the hidden state of a finished sequence is carried over from the current h buffer
+#pragma unroll
+    for (int q = 0; q < 8; q++) cst[q] = 0.f;
+    const int lc0 = (j < 16 ? 0 : 64) + 16 * wave + (j & 15);     // gates i | j
+    const int lc1 = (j < 16 ? 128 : 192) + 16 * wave + (j & 15);  // gates f | o
+    const float bl0 = Wb[GA_OFF_BL + lc0], bl1 = Wb[GA_OFF_BL + lc1];
+    // the wave's 72 x 64 block of the LSTM kernel stays in registers for the whole sequence (72 VGPRs, dead afterwards)
+    constexpr int LKP = (7 + GA_H + 1) / 2;
+    float wl0[LKP], wl1[LKP];
+#pragma unroll
+    for (int p = 0; p < LKP; p++) {
+        const int k = 2 * p + half;
+        wl0[p] = k < 7 + GA_H ? Wb[GA_OFF_WL + (size_t)k * GA_W + lc0] : 0.f;
+        wl1[p] = k < 7 + GA_H ? Wb[GA_OFF_WL + (size_t)k * GA_W + lc1] : 0.f;
+    }
+    __syncthreads();
+    int tmax = 0;
+    for (int g = 0; g < AG; g++) tmax = nseq[g] > tmax ? nseq[g] : tmax;
+    uint32_t live_until = 0;  // sequence lengths (<= 10) of this lane's eight agents, 4 bits each
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const int r = rbase + q;
+        live_until |= (uint32_t)nseq[(r & 3) + 8 * (r >> 2) + 4 * half] << (4 * q);
+    }
+    for (int t = 0; t < tmax; t++) {
+        const float* hcur = hb + ((t + tmax) & 1) * HB;
+        float* hnext = hb + ((t + tmax + 1) & 1) * HB;
+        const float* xt = xs + t * 7 * AG;
+        ga_f32x16 a0 = ga_splat(bl0), a1 = ga_splat(bl1);
+#pragma unroll
+        for (int p = 0; p < LKP; p++) {
+            // input row k = 2 p + half of concat[x_t (7), h (64), 0]: rows 0..6 from xs, row k >= 7 is row k - 3 of the h buffer
+            float a;
+            if (p < 3) a = xt[(2 * p + half) * AG + j];
+            else if (p == 3) a = half ? hcur[4 * AG + j] : xt[6 * AG + j];
+            else a = hcur[(2 * p + half - 3) * AG + j];
+            a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wl0[p], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wl1[p], a1, 0, 0, 0);
+        }
+        // lane j < 16 holds (i, f) of its unit and needs (j, o) from lane j + 16 for regs 0..7; lane j >= 16 holds (j, o) and
+        // needs (i, f) from lane j - 16 for regs 8..15
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            // v_permlane16_swap (gfx950): rows 1 / 3 of the first operand <-> rows 0 / 2 of the second, i.e. exactly this exchange:
+            // afterwards the first result holds gate i (f) and the second gate j (o) of the lane's own (unit, agent) cell
+            const auto s0 = __builtin_amdgcn_permlane16_swap(__float_as_uint(a0[q]), __float_as_uint(a0[8 + q]), false, false);
+            const auto s1 = __builtin_amdgcn_permlane16_swap(__float_as_uint(a1[q]), __float_as_uint(a1[8 + q]), false, false);
+            const float gi = __uint_as_float(s0[0]), gj = __uint_as_float(s0[1]);
+            const float gf = __uint_as_float(s1[0]), go = __uint_as_float(s1[1]);
+            const int r = rbase + q;
+            const int agent = (r & 3) + 8 * (r >> 2) + 4 * half;
+            float hnew = hcur[(4 + unit) * AG + agent];
+            if (t < (int)((live_until >> (4 * q)) & 15u)) {
+                const float c = ga_fast_sigmoid(gf + 1.0f) * cst[q] + ga_fast_sigmoid(gi) * ga_fast_tanh(gj);
+                cst[q] = c;
+                hnew = ga_fast_sigmoid(go) * ga_fast_tanh(c);
+            }
+            hnext[(4 + unit) * AG + agent] = hnew;
+        }
+        __syncthreads();  // the other buffer is complete; everyone has finished reading this one
+    }
+    // ---- layer1: concat[host(4), h(64)] -> 256, ReLU: the final h buffer as it stands -------------------------------------
+    const float* hfin = hb;
+    const int c0 = 64 * wave + j, c1 = 64 * wave + 32 + j;
+    {
+        ga_f32x16 a0 = ga_splat(Wb[GA_OFF_B1 + c0]), a1 = ga_splat(Wb[GA_OFF_B1 + c1]);
+        ga_mfma_layer<8, 2>(hfin, 4 + GA_H, Wb + GA_OFF_W1, GA_W, c0, c1, true, a0, a1);
+        ga_store_tile_relu(za, c0, a0);
+        ga_store_tile_relu(za, c1, a1);
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int layer = 0; layer < 2; layer++) {
+        const int ob = layer == 0 ? GA_OFF_B2 : GA_OFF_B3;
+        ga_f32x16 a0 = ga_splat(Wb[ob + c0]), a1 = ga_splat(Wb[ob + c1]);
+        ga_mfma_layer<8, 2>(za, GA_W, Wb + (layer == 0 ? GA_OFF_W2 : GA_OFF_W3), GA_W, c0, c1, true, a0, a1);
+        __syncthreads();  // in place: every wave has read the whole input
+        ga_store_tile_relu(za, c0, a0);
+        ga_store_tile_relu(za, c1, a1);
+        __syncthreads();
+    }
+    // ---- logits_p 256 -> 11: each wave sums its quarter of k on one tile (columns >= 11 are zero weights) ---------------------
+    {
+        ga_f32x16 a0 = ga_splat(0.f), a1 = ga_splat(0.f);
+        ga_mfma_layer<8, 1>(za + 64 * wave * AG, 64, Wb + GA_OFF_WP + (size_t)64 * wave * 11, 11, j < 11 ? j : 0, 0, j < 11, a0, a1);
+        if (j < 11) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) part[(wave * AG + (r & 3) + 8 * (r >> 2) + 4 * half) * 12 + j] = a0[r];
+        }
+    }
+    __syncthreads();
+    for (int e = n; e < AG * 11; e += 256) {
+        const int g = e / 11, o = e - g * 11;
+        logit[g * 12 + o] = Wb[GA_OFF_BP + o] + ((part[g * 12 + o] + part[(AG + g) * 12 + o]) + (part[(2 * AG + g) * 12 + o] + part[(3 * AG + g) * 12 + o]));
+    }
+    __syncthreads();
+    if (n < AG && tile + n < B) {
+        const int a = agent_idx[tile + n];
+        float mx = logit[n * 12];
+        int best = 0;
+        for (int o = 1; o < 11; o++)
+            if (logit[n * 12 + o] > mx) { mx = logit[n * 12 + o]; best = o; }
+        if (probs) {
+            float ex[11], s = 0.f;
+            for (int o = 0; o < 11; o++) { ex[o] = expf(logit[n * 12 + o] - mx); s += ex[o]; }
+            for (int o = 0; o < 11; o++) probs[(size_t)(tile + n) * 11 + o] = (ex[o] / s + 1e-4f) / (1.0f + 1e-4f * 11);
+        }
+        if (action_index) action_index[tile + n] = best;
+        double a0, a1;
+        if (best < 5) { a0 = 1.0; a1 = -kPi / 6 + (double)best * (kPi / 12); }
+        else if (best < 8) { a0 = 0.5; a1 = -kPi / 6 + (double)(best - 5) * (kPi / 6); }
+        else { a0 = 0.0; a1 = -kPi / 6 + (double)(best - 8) * (kPi / 6); }
+        if (ext_actions) {
+            ext_actions[2 * (size_t)a] = (float)(pref[a] * a0);
+            ext_actions[2 * (size_t)a + 1] = (float)a1;
+        }
+    }
+}
