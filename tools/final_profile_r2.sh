@@ -36,6 +36,9 @@ python bench.py --no-cpu-baseline --worlds 2048 --agents 20 --roll 256 --repeats
 echo sweep done
 python bench.py --config cfg4 --steps 200 --warmup 50 > $O/bench_cfg4.json 2> $O/bench_cfg4.err
 python bench.py --config cfg5 --steps 200 --warmup 50 > $O/bench_cfg5.json 2> $O/bench_cfg5.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_cfg4 -o run -- python3 bench.py --config cfg4 --steps 200 --warmup 50 --repeats 5 --no-cpu-baseline > $O/bench_cfg4_under_rocprof.json 2>/dev/null
+python tools/ga3c_ab.py > $O/ga3c_ab.txt 2>&1
+hipcc --offload-arch=gfx950 -O3 -Wno-unused-result -o /tmp/mfma_rate tools/micro/mfma_rate.hip 2>/dev/null && /tmp/mfma_rate > $O/mfma_rate.txt
 echo rows done
 CAGYM_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 512 --warmup 64 --roll 64 --repeats 5 --no-cpu-baseline > $O/rehearsal_2ranks_gloo.json 2> $O/rehearsal_2ranks_gloo.err
 echo rehearsal done

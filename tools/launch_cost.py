@@ -90,10 +90,12 @@ def part_b():
     buf = (ctypes.c_ulonglong * (W * n_wg))()
     print("Part B: per-workgroup s_memrealtime trace (10 ns ticks), %d workgroups" % n_wg)
     for n, warm in ((20, True), (20, False), (36, True), (5, True)):
-        if warm:  # queue the traced launch right behind another one (no idle gap in front of it)
-            env.rollout(64, out=traj)
-        else:
+        if not warm:  # warm: the traced launch is queued right behind another one (no idle gap in front of it)
             torch.cuda.synchronize()
+        ep0 = env.state()["episode"].clone()
+        if warm:
+            env.rollout(64, out=traj)
+            ep0 = None  # (episode counters of the launch in front are not separable; the sync'd variant reports resets)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         env.rollout(n, out=traj)
@@ -101,6 +103,12 @@ def part_b():
         torch.cuda.synchronize()
         ev_us = e0.elapsed_time(e1) * 1e3
         env.L.cagym_debug_wgtrace(buf, n_wg)
+        resets = None
+        if ep0 is not None:
+            wpw = (N + n_wg - 1) // n_wg
+            d = (env.state()["episode"] - ep0).cpu().numpy().astype(np.float64)
+            d = np.concatenate([d, np.zeros(n_wg * wpw - d.size)])
+            resets = d.reshape(n_wg, wpw).sum(1)
         T = np.frombuffer(buf, dtype=np.uint64).reshape(n_wg, W).astype(np.int64)
         t0 = T[:, 0].min()
         start, pro, end = (T[:, 0] - t0) * 0.01, (T[:, 1] - T[:, 0]) * 0.01, (T[:, 38] - t0) * 0.01
@@ -121,6 +129,12 @@ def part_b():
               "busy per step: min %.1f median %.1f max %.1f; least-squares time = %.2f + %.3f x busy us per step"
               % (np.corrcoef(steps[:, :h].sum(1), steps[:, h:].sum(1))[0, 1], np.corrcoef(tot, busy)[0, 1], busy.min() / n,
                  np.median(busy) / n, busy.max() / n, *np.polyfit(busy / n, tot / n, 1)[::-1]))
+        if resets is not None:
+            A = np.stack([np.ones(n_wg), busy / n, resets], 1)
+            coef = np.linalg.lstsq(A, tot, rcond=None)[0]
+            print("    auto-resets per workgroup in this launch: mean %.2f max %d; least squares: workgroup time = %.1f + %.2f x (busy egos per step) + %.2f x resets us; "
+                  "workgroups by resets (count: median time): %s" % (resets.mean(), resets.max(), coef[0], coef[1], coef[2],
+                  "  ".join("%d (%d): %.1f" % (r, (resets == r).sum(), np.median(tot[resets == r])) for r in sorted(set(resets.astype(int).tolist())))))
         if n == 20 and warm:
             np.save(os.path.join(ROOT, "gpurun_out", "wgtrace_20.npy"), T)
         print("    sum of steps per workgroup: min %.1f median %.1f p99 %.1f max %.1f us; XCC ids seen %s, entry median per XCC %s"

@@ -5,6 +5,9 @@ O, P = "gpurun_out/final_r2/", "profiles/r2/"
 os.makedirs(P, exist_ok=True)
 shutil.copy(O + "stats/run_kernel_stats.csv", P + "bench_4096x10_rvo_kernel_stats.csv")
 shutil.copy(O + "stats20/run_kernel_stats.csv", P + "bench_driver_cmd_20steps_kernel_stats.csv")
+shutil.copy(O + "stats_cfg4/run_kernel_stats.csv", P + "bench_cfg4_kernel_stats.csv")
+for a in ("ga3c_ab.txt", "mfma_rate.txt"):
+    shutil.copy(O + a, P + a)
 for a in ("bench_default.json", "bench_driver_cmd.json", "bench_under_rocprof.json", "bench20_under_rocprof.json", "bench_cfg4.json",
           "bench_cfg5.json", "wave_trace_4096.txt", "launch_cost.txt", "smoke.log"):
     shutil.copy(O + a, P + a)
