@@ -538,7 +538,7 @@ __device__ __forceinline__ void oas_row3(const Lds3& W, float* oas_out, int p, i
     } else {
         int before = 0;  // descending key, ties by descending index (stable sort, reversed: :28-34)
         const double2* krow = reinterpret_cast<const double2*>(W.keys + q.a * MP);
-        for (int l2 = 0; l2 < MP; l2 += 2) {
+        for (int l2 = 0; l2 < M; l2 += 2) {  // keys beyond the world's slots (and the pad of an odd M) are -inf
             const double2 kk = krow[l2 >> 1];
             before += (kk.x > kj) || (kk.x == kj && l2 + 0 > q.j);
             before += (kk.y > kj) || (kk.y == kj && l2 + 1 > q.j);
