@@ -60,7 +60,7 @@ __device__ __forceinline__ void dm_prim(int k, double& v, double& w) {  // mcts_
 
 // Tree._expansion (DecMCTS.py:201-231): one child per feasible primitive, in primitive order.
 __device__ inline void dm_expand(const uint32_t* d2, DmNode* T, int* n_nodes, int s, const DmParams& P,
-                                 unsigned long long* vis, uint32_t* win, double* cpose, int* cfeas, int tid) {
+                                 unsigned long long* vis, double* cpose, int* cfeas, int tid) {
     const int stage = T[s].stage;
     if (stage >= P.horizon || T[s].nchild != 0) return;  // uniform: every lane reads the same node
     if (tid < 9) {
@@ -76,7 +76,7 @@ __device__ inline void dm_expand(const uint32_t* d2, DmNode* T, int* n_nodes, in
     for (int k = 0; k < 9; k++) {
         if (!cfeas[k] || first + cnt >= P.node_cap) continue;  // a full pool stops growing (sized so it never is)
         const int c = first + cnt;
-        ig_visible_block(d2, cpose[3 * k], cpose[3 * k + 1], cpose[3 * k + 2], P.fov, P.range, vis, win, tid, DM_THREADS);
+        ig_visible_block(d2, cpose[3 * k], cpose[3 * k + 1], cpose[3 * k + 2], P.fov, P.range, vis, tid, DM_THREADS);
         for (int j = tid; j < IG_BEL; j += DM_THREADS) {
             T[c].observed[j] = T[s].observed[j] | vis[j];
             T[c].best_obs[j] = 0ull;
@@ -104,7 +104,6 @@ __global__ void __launch_bounds__(DM_THREADS) k_dmcts_plan(IgDev G, DmParams P, 
                                                          int32_t* n_nodes_all, DmPublished* pub_all, double* out_actions,
                                                          uint8_t* out_paths, double* out_stats) {
     __shared__ unsigned long long vis[IG_BEL], obs[IG_BEL], excl[IG_BEL], bobs[IG_BEL];
-    __shared__ uint32_t win[IG_WIN_CAP];  // visibility queries: window of the distance field (cagym_ig.h)
     __shared__ double red[DM_THREADS];
     __shared__ int redi[DM_THREADS];
     __shared__ double cpose[27];
@@ -136,7 +135,7 @@ __global__ void __launch_bounds__(DM_THREADS) k_dmcts_plan(IgDev G, DmParams P, 
             dist_n[r] = 1; dist_idx[r][0] = 0; dist_q[r][0] = 1.0;
         }
         __syncthreads();
-        dm_expand(d2, T, nn, 0, P, vis, win, cpose, cfeas, tid);
+        dm_expand(d2, T, nn, 0, P, vis, cpose, cfeas, tid);
     }
 
     for (int cycle = 0; cycle < P.Ncycles; cycle++) {
@@ -187,7 +186,7 @@ __global__ void __launch_bounds__(DM_THREADS) k_dmcts_plan(IgDev G, DmParams P, 
                 }
                 __syncthreads();
                 const int s = sh_sel;
-                dm_expand(d2, T, nn, s, P, vis, win, cpose, cfeas, tid);
+                dm_expand(d2, T, nn, s, P, vis, cpose, cfeas, tid);
                 // ---- simulation (DecMCTS.py:233-271, 296-327): Nsims random roll-outs from the selected node ----------
                 const int steps = H - T[s].stage;
                 const unsigned long long rseed = P.seed * 1000003ull + (unsigned long long)call;
@@ -202,7 +201,7 @@ __global__ void __launch_bounds__(DM_THREADS) k_dmcts_plan(IgDev G, DmParams P, 
                         dm_prim((int)k, v, wv);
                         const bool ok = ig_next_pose(d2, x, y, th, v, wv, P.xdt, P.dt, P.radius);  // uniform
                         if (ok) {
-                            ig_visible_block(d2, x, y, th, P.fov, P.range, vis, win, tid, DM_THREADS);
+                            ig_visible_block(d2, x, y, th, P.fov, P.range, vis, tid, DM_THREADS);
                             for (int j = tid; j < IG_BEL; j += DM_THREADS) obs[j] |= vis[j];
                             __syncthreads();
                         }

@@ -46,39 +46,14 @@ __device__ __forceinline__ double edf_at(const uint32_t* d2, double x, double y)
     return sqrt((double)d2[yi * CAGYM_MAPD + xi]) * IG_EDF_CELL;
 }
 
-// A window of the squared-distance field staged in LDS for one visibility query.  Every sample point of the query's sphere
-// traces is a convex combination of the sensor position and a candidate cell centre, so the window is their bounding box
-// (+ 1 cell for rounding) in UNWRAPPED cell coordinates: a negative index wraps like the reference's numpy index, an index
-// beyond the map reads as distance 0 (edf_at returns 0.0 there and sqrt(0) * 0.1 is the same 0.0).  A dependent gather
-// then costs an LDS access instead of an L2 / MALL round trip - the trace is a chain of such gathers.  A lookup outside the
-// window (or a query whose window exceeds IG_WIN_CAP) takes the global path: same values either way.
-#define IG_WIN_CAP 6144  // u32 entries (24 KB): range 5 m, fov 60 deg needs <= 55 x 92 cells
-struct EdfWin {
-    const uint32_t* d2;  // the scenario's 300 x 300 field
-    const uint32_t* w;   // LDS window or null
-    int x0, y0, W, H;
-};
-
-__device__ __forceinline__ double edf_at_win(const EdfWin& E, double x, double y) {
-    double fx = floor((x + IG_HALF) / IG_EDF_CELL), fy = floor((y + IG_HALF) / IG_EDF_CELL);
-    if (!(fx > -1e6 && fx < 1e6 && fy > -1e6 && fy < 1e6)) return 0.0;
-    int xi = (int)fx, yi = (int)fy;
-    const int lx = xi - E.x0, ly = yi - E.y0;
-    if (E.w && (unsigned)lx < (unsigned)E.W && (unsigned)ly < (unsigned)E.H) return sqrt((double)E.w[ly * E.W + lx]) * IG_EDF_CELL;
-    if (xi < 0) xi += CAGYM_MAPD;
-    if (yi < 0) yi += CAGYM_MAPD;
-    if (xi < 0 || yi < 0 || xi >= CAGYM_MAPD || yi >= CAGYM_MAPD) return 0.0;
-    return sqrt((double)E.d2[yi * CAGYM_MAPD + xi]) * IG_EDF_CELL;
-}
-
 // edfMap.checkVisibility (edfMap.py:21-47); the trip count is bounded (>= 1e-3 / dist progress per trip)
-__device__ inline bool ig_check_visibility(const EdfWin& E, double px, double py, double gx, double gy) {
+__device__ inline bool ig_check_visibility(const uint32_t* d2, double px, double py, double gx, double gy) {
     double dx = gx - px, dy = gy - py;
     double dist = sqrt(dx * dx + dy * dy);
     double u = 0.05 / dist;
     for (int guard = 0; u < 1 && guard < 100000; guard++) {
         double nx = (1 - u) * px + u * gx, ny = (1 - u) * py + u * gy;
-        double md = edf_at_win(E, nx, ny);
+        double md = edf_at(d2, nx, ny);
         if (md < 0.001) return false;
         u += md / dist;
     }
@@ -98,8 +73,9 @@ __device__ __forceinline__ double ig_clamp(double v) {
 // targetMap.getVisibleCells (targetMap.py:43-84), computed by all `nthreads` threads of a block into the
 // LDS mask `vis[60]` (zeroed here).  Ends with a barrier.
 __device__ inline void ig_visible_block(const uint32_t* d2, double px, double py, double phi, double fov, double range,
-                                        unsigned long long* vis, uint32_t* win, int tid, int nthreads) {
+                                        unsigned long long* vis, int tid, int nthreads) {
     for (int j = tid; j < IG_BEL; j += nthreads) vis[j] = 0ull;
+    __syncthreads();
     double s, c;
     sincos(phi, &s, &c);
     double sl, cl, sr, cr;
@@ -117,28 +93,6 @@ __device__ inline void ig_visible_block(const uint32_t* d2, double px, double py
     ye = min(ye, IG_BEL);
     const int w = xe - xs, h = ye - ys;
     const int total = (w > 0 && h > 0) ? w * h : 0;
-    // the field window of this query (uniform over the block)
-    EdfWin E = {d2, nullptr, 0, 0, 0, 0};
-    if (win && total > 0) {
-        const double xlo = fmin(px, xs * IG_BEL_CELL - IG_HALF + IG_BEL_CELL / 2), xhi = fmax(px, (xe - 1) * IG_BEL_CELL - IG_HALF + IG_BEL_CELL / 2);
-        const double ylo = fmin(py, ys * IG_BEL_CELL - IG_HALF + IG_BEL_CELL / 2), yhi = fmax(py, (ye - 1) * IG_BEL_CELL - IG_HALF + IG_BEL_CELL / 2);
-        const double fx0 = floor((xlo + IG_HALF) / IG_EDF_CELL) - 1, fx1 = floor((xhi + IG_HALF) / IG_EDF_CELL) + 1;
-        const double fy0 = floor((ylo + IG_HALF) / IG_EDF_CELL) - 1, fy1 = floor((yhi + IG_HALF) / IG_EDF_CELL) + 1;
-        if (fx0 > -1e6 && fx1 < 1e6 && fy0 > -1e6 && fy1 < 1e6) {  // (false for NaN poses too)
-            const int W = (int)fx1 - (int)fx0 + 1, H = (int)fy1 - (int)fy0 + 1;
-            if (W > 0 && H > 0 && W <= IG_WIN_CAP && H <= IG_WIN_CAP && W * H <= IG_WIN_CAP) {
-                E.w = win; E.x0 = (int)fx0; E.y0 = (int)fy0; E.W = W; E.H = H;
-                for (int e = tid; e < W * H; e += nthreads) {
-                    const int ly = e / W, lx = e - ly * W;
-                    int xi = E.x0 + lx, yi = E.y0 + ly;
-                    if (xi < 0) xi += CAGYM_MAPD;
-                    if (yi < 0) yi += CAGYM_MAPD;
-                    win[e] = (xi < 0 || yi < 0 || xi >= CAGYM_MAPD || yi >= CAGYM_MAPD) ? 0u : d2[yi * CAGYM_MAPD + xi];
-                }
-            }
-        }
-    }
-    __syncthreads();
     for (int q = tid; q < total; q += nthreads) {
         int i = xs + q / h, j = ys + q % h;
         double cxp = (i)*IG_BEL_CELL - IG_HALF + IG_BEL_CELL / 2, cyp = (j)*IG_BEL_CELL - IG_HALF + IG_BEL_CELL / 2;
@@ -147,7 +101,7 @@ __device__ inline void ig_visible_block(const uint32_t* d2, double px, double py
         double dphi = atan2(r1, r0);
         double rn = sqrt(r0 * r0 + r1 * r1);
         if (rn < range && fabs(dphi) < fov / 2) {
-            if (ig_check_visibility(E, px, py, cxp, cyp)) atomicOr(&vis[j], 1ull << i);
+            if (ig_check_visibility(d2, px, py, cxp, cyp)) atomicOr(&vis[j], 1ull << i);
         }
     }
     __syncthreads();
@@ -268,14 +222,13 @@ __global__ void __launch_bounds__(256) k_ig_fill_belief(IgDev G, const uint8_t* 
 __global__ void __launch_bounds__(128) k_ig_visible(IgDev G, const double* poses, const int32_t* world, double fov,
                                                     double range, unsigned long long* masks) {
     __shared__ unsigned long long vis[IG_BEL];
-    __shared__ uint32_t win[IG_WIN_CAP];  // the query's window of the distance field
     const int q = blockIdx.x, tid = threadIdx.x;
     if (world[q] < 0 || world[q] >= G.N) {  // caller-supplied index out of range: empty set, nothing is read
         for (int j = tid; j < IG_BEL; j += blockDim.x) masks[(size_t)q * IG_BEL + j] = 0ull;
         return;
     }
     const uint32_t* d2 = G.d2 + (size_t)ig_scenario(G, world[q]) * CAGYM_MAPD * CAGYM_MAPD;
-    ig_visible_block(d2, poses[3 * q], poses[3 * q + 1], poses[3 * q + 2], fov, range, vis, win, tid, blockDim.x);
+    ig_visible_block(d2, poses[3 * q], poses[3 * q + 1], poses[3 * q + 2], fov, range, vis, tid, blockDim.x);
     for (int j = tid; j < IG_BEL; j += blockDim.x) masks[(size_t)q * IG_BEL + j] = vis[j];
 }
 
@@ -284,7 +237,6 @@ __global__ void __launch_bounds__(256) k_ig_update(IgDev G, const double* poses,
                                                    const double* dets, const int32_t* n_det, int P, int Dmax,
                                                    double fov, double range, unsigned long long* observed) {
     __shared__ unsigned long long vis[IG_BEL];
-    __shared__ uint32_t win[IG_WIN_CAP];  // the query's window of the distance field
     __shared__ unsigned long long uni[IG_BEL];
     const int w = blockIdx.x, tid = threadIdx.x;
     const uint32_t* d2 = G.d2 + (size_t)ig_scenario(G, w) * CAGYM_MAPD * CAGYM_MAPD;
@@ -296,7 +248,7 @@ __global__ void __launch_bounds__(256) k_ig_update(IgDev G, const double* poses,
     for (int p = 0; p < np; p++) {
         const double* pose = poses + ((size_t)w * P + p) * 3;
         const double px = pose[0], py = pose[1], phi = pose[2];
-        ig_visible_block(d2, px, py, phi, fov, range, vis, win, tid, blockDim.x);
+        ig_visible_block(d2, px, py, phi, fov, range, vis, tid, blockDim.x);
         double s, c;
         sincos(phi, &s, &c);
         const int nd = n_det[w * P + p];
@@ -369,7 +321,6 @@ __global__ void __launch_bounds__(128) k_ig_rollouts(IgDev G, const double* pose
                                                      unsigned long long seed, double* rewards, uint8_t* actions,
                                                      double* final_pose, unsigned long long* observed_out) {
     __shared__ unsigned long long vis[IG_BEL];
-    __shared__ uint32_t win[IG_WIN_CAP];  // the query's window of the distance field
     __shared__ unsigned long long obs[IG_BEL];
     __shared__ double red[128];
     const int q = blockIdx.x / nsims, sim = blockIdx.x % nsims, tid = threadIdx.x;
@@ -399,7 +350,7 @@ __global__ void __launch_bounds__(128) k_ig_rollouts(IgDev G, const double* pose
         const double wv = k % 3 == 0 ? -0.5 * kPi : (k % 3 == 1 ? 0.0 : 0.5 * kPi);
         bool ok = ig_next_pose(d2, x, y, th, v, wv, xdt, dt, rad);  // uniform across the block
         if (ok) {
-            ig_visible_block(d2, x, y, th, fov, range, vis, win, tid, blockDim.x);
+            ig_visible_block(d2, x, y, th, fov, range, vis, tid, blockDim.x);
             for (int j = tid; j < IG_BEL; j += blockDim.x) obs[j] |= vis[j];
             __syncthreads();
         }
