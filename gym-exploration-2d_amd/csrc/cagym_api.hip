@@ -643,7 +643,8 @@ int cagym_ga3c_forward(void* env, const float* weights, const float* state, cons
     DEVGUARD(e);
     // 32 agents per workgroup reuse every weight 32 times; small batches take 16 so that each CU still gets >= 2 workgroups
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    static const bool use_valu = [] { const char* g = getenv("CAGYM_GA3C"); return g && !strcmp(g, "valu"); }();
+    const char* which = getenv("CAGYM_GA3C");  // read per call: the A/B test flips it inside one process
+    const bool use_valu = which && !strcmp(which, "valu");
     if (!use_valu)  // default: the matrix-core kernel (CAGYM_GA3C=valu selects round 1's vector kernel, for A/B)
         hipLaunchKernelGGL(k_ga3c_forward_mfma, dim3((unsigned)((B + 31) / 32)), dim3(256), 0, st, weights, state, agent_idx, B,
                            e->D.pref, ext_actions, action_index, probs);

@@ -110,3 +110,40 @@ def test_hip_state_kernel_and_forward_and_behaviour():
     coll = env.u("in_collision")[np.arange(M)[None, :] < n_agents[:, None]]
     assert done.mean() > 0.9
     assert goal.mean() > 0.8 and coll.mean() < 0.1  # the trained policy does avoid collisions
+
+
+@pytest.mark.gpu
+def test_matrix_core_and_vector_forward_kernels_agree():
+    """The fp32 MFMA kernel (default) against round 1's vector kernel (CAGYM_GA3C=valu) on live states, ragged batch sizes
+    (a partial 32-agent tile, agents with 0..9 observed others): same arg-max wherever the margin is clear, probabilities to 1e-5."""
+    import os
+    import torch
+    B = importlib.import_module("gym-exploration-2d_amd.batched_env").BatchedCollisionAvoidanceEnv
+    GA3C = importlib.import_module("gym-exploration-2d_amd.ga3c").GA3CCADRLPolicy
+    N, M = 37, 10
+    rng = np.random.default_rng(3)
+    env = B(N, M, game_over_mode="all")
+    n_agents = rng.integers(1, M + 1, N).astype(np.int32)
+    env.set_scenarios(scen.random_worlds_fast(N, M, seed=8), np.full((N, M), scen.POLICY_GA3C, dtype=np.int32), scen.DYN_UNICYCLE, n_agents=n_agents)
+    env.reset()
+    policy = GA3C(env)
+    ext = torch.zeros((N, M, 2), dtype=torch.float32, device=env.device)
+    for t in range(12):
+        policy.states()
+        os.environ["CAGYM_GA3C"] = "valu"
+        try:
+            act_v, p_v = policy.forward(want_probs=True)
+        finally:
+            del os.environ["CAGYM_GA3C"]
+        act_m, p_m = policy.forward(want_probs=True)
+        torch.cuda.synchronize()
+        assert act_m.numel() == int(n_agents.sum()) or t > 0
+        pv, pm = p_v.double().cpu().numpy(), p_m.double().cpu().numpy()
+        assert np.isfinite(pm).all() and np.abs(pm.sum(1) - 1.0).max() < 1e-5
+        assert np.abs(pv - pm).max() <= 1e-5, t
+        top2 = np.sort(pv, axis=1)[:, -2:]
+        clear = (top2[:, 1] - top2[:, 0]) > 1e-4
+        assert (act_v.cpu().numpy() == act_m.cpu().numpy())[clear].all()
+        policy.act(ext)
+        env.step(ext)
+    env.close()
