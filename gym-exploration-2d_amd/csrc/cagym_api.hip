@@ -622,6 +622,7 @@ int cagym_debug_stamps(unsigned long long* out16, int reset) {
 #endif
 
 #ifdef CAGYM_WAVETRACE
+int cagym_debug_wavetrace_select(int wg) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_wt_wg), &wg, sizeof(int)); }
 int cagym_debug_wavetrace(unsigned long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wavetrace), sizeof(unsigned long long) * CAGYM_WT_STEPS * CAGYM_WT_POINTS * 8);
 }

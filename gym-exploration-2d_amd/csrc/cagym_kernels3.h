@@ -68,11 +68,11 @@ __device__ unsigned long long g_wgtrace[CAGYM_WGTRACE_MAXWG * CAGYM_WGTRACE_W];
 #ifdef CAGYM_WAVETRACE
 #define CAGYM_WT_STEPS 24
 #define CAGYM_WT_POINTS 16
-#define CAGYM_WT_WG 7
+__device__ int g_wt_wg = 7;  // the traced workgroup (cagym_debug_wavetrace_select)
 __device__ unsigned long long g_wavetrace[CAGYM_WT_STEPS * CAGYM_WT_POINTS * 8];
 #define WAVETRACE(t, point)                                                                                           \
     do {                                                                                                              \
-        if ((threadIdx.x & 63) == 0 && blockIdx.x == CAGYM_WT_WG && (t) < CAGYM_WT_STEPS)                             \
+        if ((threadIdx.x & 63) == 0 && (int)blockIdx.x == g_wt_wg && (t) < CAGYM_WT_STEPS)                             \
             g_wavetrace[((t) * CAGYM_WT_POINTS + (point)) * 8 + (threadIdx.x >> 6)] = __builtin_amdgcn_s_memtime();   \
     } while (0)
 #else
@@ -777,7 +777,7 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
 #else
 #ifdef CAGYM_WAVETRACE
                         orca_lp_group<GW, TWO, (MT > 0 ? MT - 1 : 0)>(W.sorted, W.lp3 + 2 * (tid & ~(GW - 1)), a, j, nn, rad, pv.x, pv.y, vx, vy, AS, &W.flag[3], nullptr,
-                                                                  (blockIdx.x == CAGYM_WT_WG && t < CAGYM_WT_STEPS && base == 0) ? g_wavetrace + (size_t)t * CAGYM_WT_POINTS * 8 : nullptr);
+                                                                  ((int)blockIdx.x == g_wt_wg && t < CAGYM_WT_STEPS && base == 0) ? g_wavetrace + (size_t)t * CAGYM_WT_POINTS * 8 : nullptr);
 #else
                         orca_lp_group<GW, TWO, (MT > 0 ? MT - 1 : 0)>(W.sorted, W.lp3 + 2 * (tid & ~(GW - 1)), a, j, nn, rad, pv.x, pv.y, vx, vy, AS, &W.flag[3]);
 #endif
