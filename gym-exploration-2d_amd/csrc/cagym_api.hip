@@ -598,14 +598,48 @@ int cagym_get_state(void* env, cagym_state_ptrs* out) {
     return CAGYM_OK;
 }
 
+static void launch_ga3c_state(Env* e, int max_observed, const int32_t* agent_idx, long long rows, const int32_t* B_dev, float* state,
+                              hipStream_t st) {
+    if (e->cfg.max_agents <= 16)
+        hipLaunchKernelGGL(k_ga3c_state<16>, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, st, e->D, max_observed, agent_idx, (int)rows, B_dev, state);
+    else
+        hipLaunchKernelGGL(k_ga3c_state<32>, dim3((unsigned)((rows + 7) / 8)), dim3(256), 0, st, e->D, max_observed, agent_idx, (int)rows, B_dev, state);
+}
+
 int cagym_ga3c_state(void* env, int max_observed, float* state, void* stream) {
     Env* e = reinterpret_cast<Env*>(env);
     if (!e) return fail(nullptr, CAGYM_E_INVALID, "null env");
     if (!state || max_observed < 1 || max_observed > 10) return fail(e, CAGYM_E_INVALID, "bad arguments (max_observed in 1..10)");
     DEVGUARD(e);
-    size_t total = (size_t)e->cfg.n_worlds * e->cfg.max_agents;
-    hipLaunchKernelGGL(k_ga3c_state, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                       reinterpret_cast<hipStream_t>(stream), e->D, max_observed, state);
+    launch_ga3c_state(e, max_observed, nullptr, (long long)e->cfg.n_worlds * e->cfg.max_agents, nullptr, state, reinterpret_cast<hipStream_t>(stream));
+    HIPCHK(e, hipGetLastError());
+    return CAGYM_OK;
+}
+
+size_t cagym_ga3c_act_workspace_bytes(void* env) {
+    Env* e = reinterpret_cast<Env*>(env);
+    if (!e) return 0;
+    const size_t total = (size_t)e->cfg.n_worlds * e->cfg.max_agents;
+    return 256 + a16(total * sizeof(int32_t)) + total * 76 * sizeof(float);  // [count | agent list | state rows]
+}
+
+int cagym_ga3c_act(void* env, const float* weights, int max_observed, void* work, float* ext_actions, void* stream) {
+    Env* e = reinterpret_cast<Env*>(env);
+    if (!e) return fail(nullptr, CAGYM_E_INVALID, "null env");
+    if (!weights || !work || !ext_actions || max_observed < 1 || max_observed > 10)
+        return fail(e, CAGYM_E_INVALID, "bad arguments (max_observed in 1..10)");
+    DEVGUARD(e);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const size_t total = (size_t)e->cfg.n_worlds * e->cfg.max_agents;
+    int32_t* count = reinterpret_cast<int32_t*>(work);
+    int32_t* idx = reinterpret_cast<int32_t*>(reinterpret_cast<unsigned char*>(work) + 256);
+    float* state = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(work) + 256 + a16(total * sizeof(int32_t)));
+    HIPCHK(e, hipMemsetAsync(count, 0, sizeof(int32_t), st));
+    hipLaunchKernelGGL(k_ga3c_select, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, e->D, idx, count);
+    // the list length stays on the device: both kernels are launched for the worst case and leave beyond *count
+    launch_ga3c_state(e, max_observed, idx, (long long)total, count, state, st);
+    hipLaunchKernelGGL(k_ga3c_forward_mfma, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, st, weights, state, idx, 0, count, e->D.pref,
+                       ext_actions, (int32_t*)nullptr, (float*)nullptr);
     HIPCHK(e, hipGetLastError());
     return CAGYM_OK;
 }
@@ -648,7 +682,7 @@ int cagym_ga3c_forward(void* env, const float* weights, const float* state, cons
     const bool use_valu = which && !strcmp(which, "valu");
     if (!use_valu)  // default: the matrix-core kernel (CAGYM_GA3C=valu selects round 1's vector kernel, for A/B)
         hipLaunchKernelGGL(k_ga3c_forward_mfma, dim3((unsigned)((B + 31) / 32)), dim3(256), 0, st, weights, state, agent_idx, B,
-                           e->D.pref, ext_actions, action_index, probs);
+                           (const int32_t*)nullptr, e->D.pref, ext_actions, action_index, probs);
     else if (B <= 16 * 1024)
         hipLaunchKernelGGL(k_ga3c_forward<16>, dim3((unsigned)((B + 15) / 16)), dim3(256), 0, st, weights, state, agent_idx, B,
                            e->D.pref, ext_actions, action_index, probs);

@@ -276,9 +276,11 @@ __device__ __forceinline__ void ga_store_tile_relu(float* act, int neuron, const
 
 // 200 VGPRs (72 of them the LSTM weights) -> 2 workgroups per CU; forcing 3 spills weights and measures the same
 __global__ void __launch_bounds__(256, 2) k_ga3c_forward_mfma(const float* __restrict__ Wb, const float* __restrict__ state,
-                                                           const int32_t* __restrict__ agent_idx, int B,
-                                                           const double* __restrict__ pref, float* ext_actions,
-                                                           int32_t* action_index, float* probs) {
+                                                           const int32_t* __restrict__ agent_idx, int B_host,
+                                                           const int32_t* __restrict__ B_dev, const double* __restrict__ pref,
+                                                           float* ext_actions, int32_t* action_index, float* probs) {
+    const int B = B_dev ? *B_dev : B_host;  // device-side count (cagym_ga3c_act): the grid covers the worst case
+    if ((int)blockIdx.x * 32 >= B) return;
     constexpr int AG = 32, HB = (4 + GA_H + 1) * AG;
     // One 40.6 KB LDS block (3 workgroups per CU):
     //   hb0 | hb1: [4 host features | 64 hidden | one zero row][agent], double-buffered over the LSTM steps (one barrier per step);

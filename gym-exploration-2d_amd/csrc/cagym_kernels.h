@@ -568,58 +568,97 @@ __global__ void __launch_bounds__(256) k_rasterize(const double* obst, const int
     }
 }
 
-// GA3CCADRLPolicy.agents_to_ga3c_cadrl_state (policies/GA3CCADRLPolicy.py:45-106): one lane per agent slot,
-// out[N,M,76] f32 = [id, n_others, dist_to_goal, heading_ego, pref_speed, radius, 10 x 7 other-agent features],
-// others ordered by (-round(d,2), p_orth), stable, last `max_observed` kept.  Zero rows for inactive slots.
-__global__ void __launch_bounds__(256) k_ga3c_state(CagymDev D, int max_observed, float* out) {
-    const size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (a >= (size_t)D.N * D.M) return;
+// GA3CCADRLPolicy.agents_to_ga3c_cadrl_state (policies/GA3CCADRLPolicy.py:45-106): LPA lanes per agent (lane j <-> other agent
+// j: its distance, sort key and feature row; the rank is a count over the keys the agent's lanes left in LDS),
+// out[N,M,76] f32 = [id, n_others, dist_to_goal, heading_ego, pref_speed, radius, 10 x 7 other-agent features], rows indexed by
+// flat agent (world * M + slot); others ordered by (-round(d,2), p_orth), stable, last `max_observed` kept.  Zero rows for
+// inactive slots.  agent_idx == null: every agent slot of the handle; else the B (or *B_dev) listed agents only - the
+// reference builds the vector for the GA3C agent alone (find_next_action is per agent).
+template <int LPA>
+__global__ void __launch_bounds__(256) k_ga3c_state(CagymDev D, int max_observed, const int32_t* __restrict__ agent_idx, int B,
+                                                    const int32_t* __restrict__ B_dev, float* out) {
+    constexpr int APB = 256 / LPA;
+    __shared__ double sk1[APB][LPA], sk2[APB][LPA];
+    const int al = threadIdx.x / LPA, j = threadIdx.x % LPA;
+    const long long total = agent_idx ? (long long)(B_dev ? *B_dev : B) : (long long)D.N * D.M;
+    if ((long long)blockIdx.x * APB >= total) return;  // uniform: the whole block is beyond the list
+    const long long q = (long long)blockIdx.x * APB + al;
+    const bool have = q < total;
+    const size_t a = have ? (agent_idx ? (size_t)agent_idx[q] : (size_t)q) : 0;
     const int world = (int)(a / D.M), i = (int)(a - (size_t)world * D.M);
     float* o = out + a * 76;
-    for (int q = 0; q < 76; q++) o[q] = 0.f;
-    const int n = D.n_agents[world];
-    if (i >= n) return;
+    if (have)
+        for (int c = j; c < 76; c += LPA) o[c] = 0.f;
+    const int n = have ? D.n_agents[world] : 0;
+    const bool ego_live = have && i < n;
     const size_t base = (size_t)world * D.M;
-    const double px = D.px[a], py = D.py[a], ri = D.radius[a];
-    double gx = D.gx[a] - px, gy = D.gy[a] - py;
-    double dist = sqrt(gx * gx + gy * gy);
-    double prx = gx, pry = gy;
-    if (dist > 1e-8) { prx = gx / dist; pry = gy / dist; }
-    const double orx = -pry, ory = prx;
-    int cnt = n - 1;
+    double px = 0, py = 0, ri = 0, prx = 0, pry = 0, orx = 0, ory = 0;
+    double dx = 0, dy = 0, rj = 0, ed = 0, k1 = 0, k2 = 0;
+    const bool mine = ego_live && j < n && j != i;
+    if (ego_live) {
+        px = D.px[a]; py = D.py[a]; ri = D.radius[a];
+        const double gx = D.gx[a] - px, gy = D.gy[a] - py;
+        const double dist = sqrt(gx * gx + gy * gy);
+        prx = gx; pry = gy;
+        if (dist > 1e-8) { prx = gx / dist; pry = gy / dist; }
+        orx = -pry; ory = prx;
+    }
+    if (mine) {
+        dx = D.px[base + j] - px; dy = D.py[base + j] - py;
+        rj = D.radius[base + j];
+        ed = norm2(dx, dy) - ri - rj;
+        k1 = -(rint(ed * 100.0) / 100.0);
+        k2 = dot2(dx, dy, orx, ory);
+        sk1[al][j] = k1;
+        sk2[al][j] = k2;
+    }
+    __syncthreads();  // keys of the agent's lanes; also orders the zero fill before the row stores below
+    const int cnt = n - 1;
     const int drop = cnt > max_observed ? cnt - max_observed : 0;
-    int rows = 0;
-    for (int j = 0; j < n; j++) {
-        if (j == i) continue;
-        double dx = D.px[base + j] - px, dy = D.py[base + j] - py;
-        double rj = D.radius[base + j];
-        double ed = norm2(dx, dy) - ri - rj;
-        double k1 = -(rint(ed * 100.0) / 100.0), k2 = dot2(dx, dy, orx, ory);
+    if (mine) {
         int before = 0;  // others sorted strictly before j: smaller (k1, k2), ties by lower index (stable)
         for (int l = 0; l < n; l++) {
             if (l == i || l == j) continue;
-            double ex = D.px[base + l] - px, ey = D.py[base + l] - py;
-            double el = norm2(ex, ey) - ri - D.radius[base + l];
-            double l1 = -(rint(el * 100.0) / 100.0), l2 = dot2(ex, ey, orx, ory);
+            const double l1 = sk1[al][l], l2 = sk2[al][l];
             before += (l1 < k1) || (l1 == k1 && (l2 < k2 || (l2 == k2 && l < j)));
         }
-        int row = before - drop;
-        if (row < 0) continue;
-        double vx = D.vx[base + j], vy = D.vy[base + j];
-        float* r = o + 6 + 7 * row;
-        r[0] = (float)dot2(dx, dy, prx, pry);
-        r[1] = (float)k2;
-        r[2] = (float)dot2(vx, vy, prx, pry);
-        r[3] = (float)dot2(vx, vy, orx, ory);
-        r[4] = (float)rj;
-        r[5] = (float)(ri + rj);
-        r[6] = (float)ed;
-        rows++;
+        const int row = before - drop;
+        if (row >= 0) {
+            const double vx = D.vx[base + j], vy = D.vy[base + j];
+            float* r = o + 6 + 7 * row;
+            r[0] = (float)dot2(dx, dy, prx, pry);
+            r[1] = (float)k2;
+            r[2] = (float)dot2(vx, vy, prx, pry);
+            r[3] = (float)dot2(vx, vy, orx, ory);
+            r[4] = (float)rj;
+            r[5] = (float)(ri + rj);
+            r[6] = (float)ed;
+        }
     }
-    o[0] = (float)i;
-    o[1] = (float)rows;
-    o[2] = (float)D.dist_goal[a];
-    o[3] = (float)D.heading_ego[a];
-    o[4] = (float)D.pref[a];
-    o[5] = (float)ri;
+    if (ego_live && j == i) {
+        o[0] = (float)i;
+        o[1] = (float)(cnt - drop);  // rows kept: the ranks are a permutation of 0 .. cnt - 1
+        o[2] = (float)D.dist_goal[a];
+        o[3] = (float)D.heading_ego[a];
+        o[4] = (float)D.pref[a];
+        o[5] = (float)ri;
+    }
+}
+
+// indices (world * M + slot) of the active agents whose policy id is CAGYM_POL_GA3C, compacted on the device (order within
+// the list is not fixed: every consumer treats the listed agents independently).  *count must be zero on entry.
+__global__ void __launch_bounds__(256) k_ga3c_select(CagymDev D, int32_t* idx, int32_t* count) {
+    const size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)D.N * D.M;
+    bool take = false;
+    if (a < total) {
+        const uint32_t st = D.status[a];
+        take = (st & CAGYM_FLAG_ACTIVE) && ST_POLICY(st) == CAGYM_POL_GA3C;
+    }
+    const unsigned long long m = __ballot(take);
+    const int lane = threadIdx.x & 63;
+    int basepos = 0;
+    if (lane == 0 && m) basepos = atomicAdd(count, __popcll(m));
+    basepos = __shfl(basepos, 0);
+    if (take) idx[basepos + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)a;
 }

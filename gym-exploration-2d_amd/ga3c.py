@@ -36,6 +36,11 @@ class GA3CCADRLPolicy(object):
         self.L.cagym_ga3c_state.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         self.L.cagym_ga3c_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                               C.c_void_p, C.c_void_p, C.c_void_p]
+        self.L.cagym_ga3c_act_workspace_bytes.argtypes = [C.c_void_p]
+        self.L.cagym_ga3c_act_workspace_bytes.restype = C.c_size_t
+        self.L.cagym_ga3c_act.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        self.L.cagym_ga3c_act.restype = C.c_int
+        self._work = None
         path = checkpoint if os.path.exists(checkpoint) else os.path.join(HERE, "weights", "ga3c_cadrl_%s.npz" % checkpoint)
         W = np.load(path)
         dev = benv.device
@@ -109,13 +114,22 @@ class GA3CCADRLPolicy(object):
         p = torch.softmax(y @ W["logits_kernel"] + W["logits_bias"], dim=1)
         return (p + 1e-4) / (1.0 + 1e-4 * 11)
 
-    def act(self, ext_actions=None):
+    def act(self, ext_actions=None, fused=True):
         """Fill ext_actions [N,M,2] f32 with (pref_speed * a0, a1) for every agent whose policy id is
-        POLICY_GA3C (GA3CCADRLPolicy.find_next_action, :34-43); other rows are left untouched."""
+        POLICY_GA3C (GA3CCADRLPolicy.find_next_action, :34-43); other rows are left untouched.
+        fused (default): one cagym_ga3c_act call - selection, state vectors of the selected agents and the network stay on
+        the device, no host synchronisation; fused=False: the three-call path (states of every slot, host-side index list)."""
         b = self.b
         if ext_actions is None:
             ext_actions = torch.zeros((b.N, b.M, 2), dtype=torch.float32, device=b.device)
-        ext_actions = ext_actions.contiguous()
-        self.states()
-        self.forward(ext_actions=ext_actions)
+        assert ext_actions.is_contiguous() and ext_actions.dtype == torch.float32
+        if not fused:
+            self.states()
+            self.forward(ext_actions=ext_actions)
+            return ext_actions
+        if self._work is None:
+            self._work = torch.empty((int(self.L.cagym_ga3c_act_workspace_bytes(b.h)),), dtype=torch.uint8, device=b.device)
+        with torch.cuda.device(b.device):
+            rc = self.L.cagym_ga3c_act(b.h, self.blob.data_ptr(), self.max_observed, self._work.data_ptr(), ext_actions.data_ptr(), b._stream())
+        _lib.check(self.L, b.h, rc, "cagym_ga3c_act")
         return ext_actions

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define CAGYM_VERSION 110 /* 0.1.1: cagym_config.rvo_max_neighbors, cagym_kernel_name */
+#define CAGYM_VERSION 111 /* 0.1.1: cagym_config.rvo_max_neighbors, cagym_kernel_name */
 
 enum { CAGYM_OK = 0, CAGYM_E_INVALID = -1, CAGYM_E_NODEVICE = -2, CAGYM_E_HIP = -3, CAGYM_E_NOMEM = -4,
        CAGYM_E_STATE = -5, CAGYM_E_UNSUPPORTED = -6 };
@@ -171,6 +171,14 @@ int cagym_ga3c_state(void* env, int max_observed, float* state, void* stream);
 #define CAGYM_GA3C_NWEIGHTS 170507
 int cagym_ga3c_forward(void* env, const float* weights, const float* state, const int32_t* agent_idx, int B,
                        float* ext_actions, int32_t* action_index, float* probs, void* stream);
+
+/* GA3CCADRLPolicy.find_next_action (policies/GA3CCADRLPolicy.py:34-43) for EVERY active agent whose policy id is
+ * CAGYM_POL_GA3C, in one call and without a host round trip: their indices are compacted on the device, their state
+ * vectors built (only theirs, as the reference does per agent), the network evaluated and (pref_speed * a0, a1) written to
+ * their rows of ext_actions [N*M, 2] f32; other rows are untouched.  work: caller-owned DEVICE scratch of
+ * cagym_ga3c_act_workspace_bytes(env) bytes (its contents are overwritten; layout private). */
+size_t cagym_ga3c_act_workspace_bytes(void* env);
+int cagym_ga3c_act(void* env, const float* weights, int max_observed, void* work, float* ext_actions, void* stream);
 
 /* ---- information-gain planner primitives (cfg 5).  All pointers DEVICE.  A visibility set is a
  * [60] u64 mask: bit i of word j <=> belief cell (i, j) (x index i, y index j; 0.5 m cells over 30x30 m). ---- */

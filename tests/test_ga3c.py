@@ -144,6 +144,45 @@ def test_matrix_core_and_vector_forward_kernels_agree():
         top2 = np.sort(pv, axis=1)[:, -2:]
         clear = (top2[:, 1] - top2[:, 0]) > 1e-4
         assert (act_v.cpu().numpy() == act_m.cpu().numpy())[clear].all()
-        policy.act(ext)
-        env.step(ext)
+        # the fused entry (device-side selection, states of the selected agents only) writes the same actions as the three-call path
+        ext3 = torch.full((N, M, 2), 7.0, dtype=torch.float32, device=env.device)
+        extf = torch.full((N, M, 2), 7.0, dtype=torch.float32, device=env.device)
+        policy.act(ext3, fused=False)
+        policy.act(extf, fused=True)
+        torch.cuda.synchronize()
+        assert torch.equal(ext3, extf), t
+        env.step(extf)
+    env.close()
+
+
+@pytest.mark.gpu
+def test_fused_act_selects_only_ga3c_agents():
+    """cfg4's composition: agent 0 GA3C, the others RVO; worlds restart with different agent counts.  cagym_ga3c_act must touch
+    exactly the rows of the active GA3C agents and follow the restarts without any host-side index list."""
+    import torch
+    B = importlib.import_module("gym-exploration-2d_amd.batched_env").BatchedCollisionAvoidanceEnv
+    GA3C = importlib.import_module("gym-exploration-2d_amd.ga3c").GA3CCADRLPolicy
+    N, M, S = 50, 10, 150
+    rng = np.random.default_rng(5)
+    pol = np.full((S, M), scen.POLICY_RVO, dtype=np.int32)
+    pol[:, 0] = scen.POLICY_GA3C
+    pol[::3, 4] = scen.POLICY_GA3C  # some scenarios hold a second GA3C agent (only active where n_agents > 4)
+    n_agents = rng.integers(2, M + 1, S).astype(np.int32)
+    env = B(N, M, n_scenarios=S, game_over_mode="agent0")
+    env.set_scenarios(scen.random_worlds_fast(S, M, seed=2), pol, scen.DYN_UNICYCLE, n_agents=n_agents, coop=np.full((S, M), 0.5))
+    env.reset()
+    policy = GA3C(env)
+    for t in range(150):
+        extf = torch.full((N, M, 2), 7.0, dtype=torch.float32, device=env.device)
+        ext3 = torch.full((N, M, 2), 7.0, dtype=torch.float32, device=env.device)
+        policy.act(extf, fused=True)
+        policy.act(ext3, fused=False)
+        torch.cuda.synchronize()
+        assert torch.equal(extf, ext3), t
+        st = env.state()["status"].cpu().numpy().reshape(N, M)
+        want = (((st >> 8) & 15) == scen.POLICY_GA3C) & ((st & 64) != 0)  # CAGYM_FLAG_ACTIVE
+        touched = (extf.cpu().numpy() != 7.0).any(axis=2)
+        assert np.array_equal(touched, want), t
+        env.step(extf, auto_reset=True)
+    assert int(env.state()["episode"].max()) >= 1  # restarts happened
     env.close()
