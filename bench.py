@@ -228,7 +228,7 @@ def main():
         workload = ("%d worlds x %d agents%s: agent 0 GA3C-CADRL (fused LSTM-64 + 3 x FC-256 forward per step), 9 RVO/ORCA agents "
                     "among 2-10 rectangles (obstacle half-planes), LaserScan + OtherAgentsStates on every agent, auto-reset "
                     "(BASELINE configs[3])" % (N, M, " on this rank" if world_size > 1 else ""))
-        launch_mode = "per step: cagym_ga3c_state + cagym_ga3c_forward + cagym_step_autoreset (laser scan inside)"
+        launch_mode = "per step: cagym_ga3c_act (device-side selection + state vectors + fused forward, no host sync) + cagym_step_autoreset (laser scan inside)"
         kernel_name = env.kernel_name(rollout=False, auto_reset=True)
 
         def run(n_steps):

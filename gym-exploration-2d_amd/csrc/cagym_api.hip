@@ -373,6 +373,8 @@ int cagym_set_scenarios(void* env, const double* agents6, const double* heading0
                     if (m0 - m1 >= 0.0f) convex |= 1u << k;
                 }
                 memcpy(&q[12], &convex, 4);
+                // its raster footprint needs neither numpy's negative-index wrap nor clamping (laser_chunk3's shortcut)
+                q[13] = (xl > -14.7f && yl > -14.7f && xu < 14.7f && yu < 14.7f) ? 1.0f : 0.0f;
             }
             HIPCHK(e, hipMemcpyAsync(e->sc_obst_prep, prep.data(), prep.size() * sizeof(float), hipMemcpyHostToDevice, st));
         }
@@ -635,7 +637,7 @@ int cagym_ga3c_act(void* env, const float* weights, int max_observed, void* work
     int32_t* idx = reinterpret_cast<int32_t*>(reinterpret_cast<unsigned char*>(work) + 256);
     float* state = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(work) + 256 + a16(total * sizeof(int32_t)));
     HIPCHK(e, hipMemsetAsync(count, 0, sizeof(int32_t), st));
-    hipLaunchKernelGGL(k_ga3c_select, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, e->D, idx, count);
+    hipLaunchKernelGGL(k_ga3c_select, dim3((unsigned)((total + 1023) / 1024)), dim3(1024), 0, st, e->D, idx, count);
     // the list length stays on the device: both kernels are launched for the worst case and leave beyond *count
     launch_ga3c_state(e, max_observed, idx, (long long)total, count, state, st);
     hipLaunchKernelGGL(k_ga3c_forward_mfma, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, st, weights, state, idx, 0, count, e->D.pref,

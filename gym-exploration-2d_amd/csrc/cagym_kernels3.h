@@ -162,6 +162,7 @@ struct Lds3 {
     int* wsc;      // [32] scenario of the world's current episode (rectangles, raster)
     int* wnob;     // [32] rectangles of that scenario
     float4* rect;  // [worlds x Kobs x 4] the worlds' prepared rectangles (OBST only), staged at episode start
+    uint16_t* blist;  // [waves x 256] (OBST only) a wave's list of the laser beams that can meet a rectangle
     int* flag;     // [8]  0: a world was reset this step   1: OAS row chunks claimed   2: LP waves finished
                    //      3/4: some ego needed linearProgram3 this / the previous step
     float2* lpv;   // [AS] preferred (optimisation) velocity of each ego
@@ -186,7 +187,8 @@ __host__ __device__ inline size_t cagym_lds3_head(int AS) {
 __host__ __device__ inline size_t cagym_lds3_bytes(int M, int AS, int NT, int ko = 0, int lpl = 2) {
     const size_t MP = cagym_mp(M);
     return a16(cagym_lds3_head(AS)) + a16(AS * MP * 4) + (size_t)(ko + M - 1) * AS * 16 + (size_t)lpl * NT * 16 + 2 * AS * MP * 8 + a16(AS * MP) +
-           (size_t)(AS / M) * (ko / 2) * 64;  // staged rectangles: worlds x Kobs x 4 float4
+           (size_t)(AS / M) * (ko / 2) * 64 +  // staged rectangles: worlds x Kobs x 4 float4
+           (lpl == 4 ? (size_t)(NT / CAGYM_WAVE) * 512 : 0);  // OBST: per-wave beam lists
 }
 
 __device__ __forceinline__ Lds3 carve_lds3(unsigned char* smem, int M, int AS, int NT, int ko = 0, int lpl = 2) {
@@ -224,6 +226,7 @@ __device__ __forceinline__ Lds3 carve_lds3(unsigned char* smem, int M, int AS, i
     W.gap = W.keys + AS * MP;
     W.hit = reinterpret_cast<uint8_t*>(W.gap + AS * MP);
     W.rect = reinterpret_cast<float4*>(reinterpret_cast<unsigned char*>(W.hit) + a16(AS * MP));
+    W.blist = reinterpret_cast<uint16_t*>(reinterpret_cast<unsigned char*>(W.rect) + (size_t)(AS / M) * (ko / 2) * 64);
     return W;
 }
 
@@ -588,32 +591,116 @@ __device__ __forceinline__ void ego_obs3(const CagymDev& D, const Lds3& W, float
     }
 }
 
-// LaserScanSensor of agent slot a, beam b (16 beams x 16 samples gathered from the world's bit-packed raster, L2-resident)
-__device__ __forceinline__ void laser_beam3(const CagymDev& D, const Lds3& W, float* laser_out, int a, int b, int M, int wpw,
-                                            uint32_t inv_m) {
-    if (a >= wpw * M) return;
-    const int wl = (int)__umulhi((uint32_t)a, inv_m);
-    const int slot = a - wl * M;
-    const int world = blockIdx.x * wpw + wl;
-    if (world >= D.N) return;
-    float v = 0.f;
-    if (slot < W.wn[wl]) {
-        const int sidx = W.wsc[wl];
-        const uint32_t* map = (D.map_bits && D.sc_nobst[sidx] > 0) ? D.map_bits + (size_t)sidx * CAGYM_MAPD * CAGYM_MAPW : nullptr;
-        v = laserscan_beam(map, W.tpx[a], W.tpy[a], W.th[a], W.tr[a], b);  // (the count is an L2 hit; the raster gathers dominate)
+// LaserScanSensor.sense restricted to the samples klo..khi of beam b (every sample outside can be shown not to hit): the running
+// hit count of sensors/LaserScanSensor.py:45-58 only changes at hits, so "the last sample whose count is 1" is sample 15 when
+// exactly one hit lies in the interval, the sample before the second hit when there are more, none without a hit.
+__device__ __forceinline__ float laserscan_beam_range(const uint32_t* map, double px, double py, double h, double radius, int b,
+                                                      int klo, int khi) {
+    int egx, egy;
+    const bool ego_in = world_to_cell(px, py, egx, egy);
+    const double rr = radius / 0.1, r2 = rr * rr;
+    const double astep = (kPi - (-kPi)) / 15.0, rstep = 2 * kPi / 16;
+    const double ang0 = b == 15 ? kPi : (double)b * astep + (-kPi);
+    double sa, ca;
+    sincos(ang0 + h, &sa, &ca);
+    int count = 0, last = -1;
+    for (int k = klo; k <= khi; k++) {
+        const double rg = 0.0 + (double)k * rstep;
+        const double x = px + rg * ca, y = py + rg * sa;
+        int gx, gy;
+        bool in = world_to_cell(x, y, gx, gy);
+        if (in && ego_in) {
+            const double dx = (double)(gy - egy), dy = (double)(gx - egx);
+            in = !(dx * dx + dy * dy < r2);
+        }
+        const bool hit = in && map_bit(map, gx, gy);
+        count += hit ? 1 : 0;
+        if (count == 1) last = k;
     }
-    laser_out[((size_t)world * M + slot) * 16 + b] = v;
+    if (count == 1) last = 15;  // no further hit beyond the interval: the count stays 1 to the end of the beam
+    const double range = last >= 0 ? 0.0 + (double)last * rstep : 6.0;
+    return (float)(1 - range / 6);
+}
+
+// LaserScan of 16 agent slots (256 beams) by one wave.  An occupied raster cell reaches at most one cell (0.1 m) beyond its
+// rectangle, so a beam whose segment misses every rectangle of the world inflated by 0.25 m reads 0.0 (= 1 - 6/6) without looking
+// at the raster, and a beam that meets some only needs the samples inside those crossings.  Four cheap passes (fp32 slab test
+// against the staged rectangles) compact the beams that need the raster into the wave's list; the fp64 sampling then runs on
+// dense lanes.  A rectangle that leaves the map (numpy's negative-index wrap puts its cells elsewhere) or unstaged rectangles
+// (no RVO agent among them: ko == 0) disable the shortcut: every beam of the world is sampled in full.
+__device__ __forceinline__ void laser_chunk3(const CagymDev& D, const Lds3& W, float* laser_out, int chunk, int M, int wpw, uint32_t inv_m, int ko) {
+    const int lane = threadIdx.x & (CAGYM_WAVE - 1), wave = threadIdx.x / CAGYM_WAVE;
+    uint16_t* lst = W.blist + wave * 256;
+    const float rstep = (float)(2 * kPi / 16), reach = 15.0f * rstep + 0.05f, infl = 0.25f;
+    int n = 0;
+    for (int pass = 0; pass < 4; pass++) {
+        const int al = pass * 4 + (lane >> 4), a = chunk * 16 + al, b = lane & 15;
+        bool need = false;
+        int klo = 0, khi = 15;
+        if (a < wpw * M) {
+            const int wl = (int)__umulhi((uint32_t)a, inv_m);
+            const int slot = a - wl * M;
+            const int world = blockIdx.x * wpw + wl;
+            if (world < D.N) {
+                if (slot < W.wn[wl]) {
+                    if (ko <= 0) {
+                        need = D.map_bits && D.sc_nobst[W.wsc[wl]] > 0;
+                    } else if (W.wnob[wl] > 0) {
+                        const double astep = (kPi - (-kPi)) / 15.0;
+                        const double ang0 = b == 15 ? kPi : (double)b * astep + (-kPi);
+                        float sa, ca;
+                        __sincosf((float)(ang0 + W.th[a]), &sa, &ca);
+                        const float px = (float)W.tpx[a], py = (float)W.tpy[a];
+                        const float icx = 1.0f / ca, icy = 1.0f / sa;
+                        float tlo = INFINITY, thi = -INFINITY;
+                        const float4* R = W.rect + (size_t)wl * D.Kobs * 4;
+                        for (int k = 0; k < W.wnob[wl]; k++) {
+                            const float4 r = R[4 * k];
+                            if (R[4 * k + 3].y != 1.0f) { tlo = 0.f; thi = reach; continue; }  // leaves the map: no shortcut
+                            const float tx1 = (r.x - infl - px) * icx, tx2 = (r.z + infl - px) * icx;
+                            const float ty1 = (r.y - infl - py) * icy, ty2 = (r.w + infl - py) * icy;
+                            const float t1 = fmaxf(fmaxf(fminf(tx1, tx2), fminf(ty1, ty2)), 0.f);
+                            const float t2 = fminf(fminf(fmaxf(tx1, tx2), fmaxf(ty1, ty2)), reach);
+                            if (t1 <= t2) { tlo = fminf(tlo, t1); thi = fmaxf(thi, t2); }
+                        }
+                        need = tlo <= thi;
+                        if (need) {
+                            klo = (int)floorf((tlo - 0.05f) / rstep);
+                            khi = (int)ceilf((thi + 0.05f) / rstep);
+                            klo = klo < 0 ? 0 : klo;
+                            khi = khi > 15 ? 15 : khi;
+                        }
+                    }
+                }
+                if (!need) laser_out[((size_t)world * M + slot) * 16 + b] = 0.f;  // inactive slot, empty map, or no rectangle in reach
+            }
+        }
+        const unsigned long long m = __ballot(need);
+        if (need) lst[n + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)((al << 12) | (b << 8) | (klo << 4) | khi);
+        n += __popcll(m);
+    }
+    for (int base = 0; base < n; base += CAGYM_WAVE) {  // (a wave's LDS accesses complete in order: the list is its own)
+        if (base + lane < n) {
+            const int e = lst[base + lane];
+            const int a = chunk * 16 + (e >> 12), b = (e >> 8) & 15;
+            const int wl = (int)__umulhi((uint32_t)a, inv_m);
+            const int slot = a - wl * M;
+            const int world = blockIdx.x * wpw + wl;
+            const uint32_t* map = D.map_bits + (size_t)W.wsc[wl] * CAGYM_MAPD * CAGYM_MAPW;
+            laser_out[((size_t)world * M + slot) * 16 + b] = laserscan_beam_range(map, W.tpx[a], W.tpy[a], W.th[a], W.tr[a], b, (e >> 4) & 15, e & 15);
+        }
+    }
 }
 
 // claim-and-process loop of the observation workers: chunks 0 .. nck-1 are 64 directed pairs each, chunk nck is the
-// scalar-observation store of the agent slots, chunks nck+1 .. are 4 agents x 16 laser beams each (when asked for).  Every wave of the workgroup may call it; a wave leaves when the
+// scalar-observation store of the agent slots, chunks nck+1 .. are 16 agents x 16 laser beams each (when asked for).  Every wave of the workgroup may call it; a wave leaves when the
 // counter has run past the last chunk (every wave reaches that: the counter only grows).
 template <bool OBST>
 __device__ __forceinline__ void observation_chunks3(const CagymDev& D, const Lds3& W, const CagymOut& o, int npairs, int M, int MP,
-                                                    int K, int wpw, int worlds_valid, uint32_t inv_m) {
+                                                    int K, int wpw, int worlds_valid, uint32_t inv_m, int ko = 0) {
     const int lane = threadIdx.x & (CAGYM_WAVE - 1);
     const int nck = (npairs + CAGYM_WAVE - 1) / CAGYM_WAVE;
-    const int nlaser = (OBST && o.laserscan) ? (wpw * M + 3) / 4 : 0;
+    const int nlaser = (OBST && o.laserscan) ? (wpw * M + 15) / 16 : 0;
     for (;;) {
         int c = 0;
         if (lane == 0) c = __hip_atomic_fetch_add(&W.flag[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -624,7 +711,7 @@ __device__ __forceinline__ void observation_chunks3(const CagymDev& D, const Lds
         } else if (c == nck) {
             ego_obs3(D, W, o.obs_ego, lane, M, wpw, inv_m);
         } else if (OBST) {
-            laser_beam3(D, W, o.laserscan, (c - nck - 1) * 4 + (lane >> 4), lane & 15, M, wpw, inv_m);
+            laser_chunk3(D, W, o.laserscan, c - nck - 1, M, wpw, inv_m, ko);
         }
     }
 }
@@ -850,7 +937,7 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
 #ifndef CAGYM_NO_LAG_PRIORITY
             __builtin_amdgcn_s_setprio(0);
 #endif
-            observation_chunks3<OBST>(D, W, o_prev, npairs, M, MP, K, C.wpw, C.worlds_valid, inv_m);
+            observation_chunks3<OBST>(D, W, o_prev, npairs, M, MP, K, C.wpw, C.worlds_valid, inv_m, ko);
 #ifndef CAGYM_NO_LAG_PRIORITY
             if (lagging) __builtin_amdgcn_s_setprio(3);
             else __builtin_amdgcn_s_setprio(1);
@@ -995,7 +1082,7 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
         WAVETRACE(t, 11);
         // ---- rare: a world restarted on its next scenario -> everything derived from the old episode is rebuilt -------------
         if (AUTO_RESET && W.flag[0]) {
-            if (OBST && ko > 0 && more) {  // the restarted worlds' rectangles
+            if (OBST && ko > 0) {  // the restarted worlds' rectangles (also behind the last step: the epilogue's scan uses them)
                 stage_rects3(D, W, C.wpw, C.worlds_valid);
                 __syncthreads();
             }
@@ -1024,7 +1111,7 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
     // ---- epilogue: observation of the last step on every wave, agent records -> HBM ------------------------------------------
     {
         const CagymOut o_last = out_slice3(out, n_steps - 1, (size_t)D.N, NM, M);
-        observation_chunks3<OBST>(D, W, o_last, npairs, M, MP, K, C.wpw, C.worlds_valid, inv_m);
+        observation_chunks3<OBST>(D, W, o_last, npairs, M, MP, K, C.wpw, C.worlds_valid, inv_m, ko);
         if (C.valid) {
             const Agent A = lds3_load_agent(W, threadIdx.x);  // own lane's record, written by this lane
             store_agent(D, A, (size_t)C.world * M + C.slot, true);

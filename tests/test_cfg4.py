@@ -113,3 +113,41 @@ def test_rollout_and_autoreset_with_laserscan():
         assert torch.equal(traj["ego"][t], c.env.obs_ego), t
     assert resets > 0
     assert float(traj["laserscan"].max()) > 0.0  # walls were seen
+
+
+def test_fused_laserscan_shortcut_with_rectangles_leaving_the_map():
+    """The in-kernel scan skips beams that cannot meet a rectangle and samples only inside the crossings; rectangles that
+    leave the 30 m map (their raster cells wrap like numpy's negative indices) and agents next to the map edge must take the
+    full path.  Fused rollout scans == the on-demand full scan (cagym_laserscan) of the same states, bit for bit."""
+    import torch
+    N, M, K, T = 24, 6, 4, 120
+    rng = np.random.default_rng(11)
+    a6 = np.zeros((N, M, 6))
+    a6[..., 0:2] = rng.uniform(-13.5, 13.5, (N, M, 2))
+    a6[..., 2:4] = rng.uniform(-13.5, 13.5, (N, M, 2))
+    a6[..., 4] = 0.3 + 0.2 * rng.random((N, M))
+    a6[..., 5] = 1.0
+    obst = np.zeros((N, K, 4))
+    n_obst = np.full(N, K, dtype=np.int32)
+    for w in range(N):
+        obst[w, 0] = (13.0, -2.0 + w * 0.1, 16.0, 1.0)       # leaves the map on the right
+        obst[w, 1] = (-16.5, 3.0, -13.5, 5.0)                # leaves it on the left
+        obst[w, 2] = (-3.0 + 0.2 * w, 13.5, 2.0, 15.6)       # leaves it at the top
+        obst[w, 3] = (-1.0, -1.5, 1.2, 0.9)                  # well inside
+    n_obst[::3] = 4
+    n_obst[1::3] = 1  # only the rectangle that leaves the map
+    pol = np.full((N, M), scen.POLICY_NONCOOP, dtype=np.int32)
+    pol[:, 0] = scen.POLICY_RVO
+    a, c = (_hip(N=N, M=M, max_obstacles=K, game_over_mode=1, laserscan=True) for _ in range(2))
+    for e in (a, c):
+        e.set_scenario(a6, pol, scen.DYN_UNICYCLE, coop=np.full((N, M), 0.5), obstacles=obst, n_obst=n_obst)
+        e.reset()
+    traj = a.env.rollout(T, auto_reset=False)
+    seen = 0
+    for t in range(T):
+        c.env.step()
+        full = c.env.sense_laserscan().clone()  # k_laserscan: all 16 samples of all 16 beams
+        assert torch.equal(traj["laserscan"][t], full), t
+        assert torch.equal(c.env.obs_laser, full), t
+        seen += int((full > 0).sum())
+    assert seen > 0
