@@ -316,8 +316,9 @@ int cagym_set_scenarios(void* env, const double* agents6, const double* heading0
             const Spec2 sp = spec2(e);
             const int as = cagym_as((int)M, sp.wpw);
             if (e->generation != 3) return fail(e, CAGYM_E_UNSUPPORTED, "RVO agents among obstacles need the generation-3 kernels");
-            // LP group capacity; the obstacle-neighbour lists (8 B per candidate + 4 B per work item) borrow the LP3 scratch
-            if (2 * K + (int)M - 1 > 4 * gw || (size_t)2 * K * as * 12 > (size_t)4 * sp.nt * 16 || lds3_bytes(e, true, true) > 160 * 1024)
+            // LP group capacity; coverage bit masks (<= 32 obstacle lines per ego); the obstacle-neighbour lists (8 B per candidate + 4 B per
+            // work item + 1 B per rank) borrow the LP3 scratch
+            if (2 * K + (int)M - 1 > 4 * gw || 2 * K > 32 || (size_t)2 * K * as * 13 > (size_t)4 * sp.nt * 16 || lds3_bytes(e, true, true) > 160 * 1024)
                 return fail(e, CAGYM_E_UNSUPPORTED, "too many rectangles per world for RVO agents at this max_agents (2 * max_obstacles + max_agents - 1 half-planes per ego)");
             if (obstacles)
                 for (size_t sc = 0; sc < S; sc++)

@@ -320,6 +320,38 @@ __device__ __forceinline__ bool wall_collision(const uint32_t* map, double px, d
     double rr = radius / 0.1, r2 = rr * rr;
     int R = (int)ceil(rr) + 1;
     if (R > 64) R = 64;
+    if (R <= 8) {
+        // the usual case (radius <= 0.7 m).  The half-width w(|dy|) = largest integer with w^2 + dy^2 < r2 (capped at R, the
+        // reference's window) only shrinks as |dy| grows: one decrementing sweep gives all of them without a square root;
+        // then the <= 17 rows x <= 2 words are requested together (the raster is L2-resident: the latency is what costs).
+        int wd[9];
+        int w = R;
+#pragma unroll
+        for (int dy = 0; dy <= 8; dy++) {
+            if (dy <= R) {
+                while (w >= 0 && !((double)w * (double)w + (double)dy * (double)dy < r2)) w--;
+                wd[dy] = w;
+            } else {
+                wd[dy] = -1;
+            }
+        }
+        uint32_t acc = 0u;
+#pragma unroll
+        for (int k = -8; k <= 8; k++) {
+            const int ww = wd[k < 0 ? -k : k], y = pi + k;
+            const bool ok = ww >= 0 && y >= 0 && y < CAGYM_MAPD;
+            int x0 = pj - ww, x1 = pj + ww;
+            x0 = x0 < 0 ? 0 : x0;
+            x1 = x1 >= CAGYM_MAPD ? CAGYM_MAPD - 1 : x1;
+            const int w0 = x0 >> 5, w1 = x1 >> 5;  // the span is <= 17 cells: one or two words
+            const uint32_t* row = map + (ok ? y : 0) * CAGYM_MAPW;
+            const uint32_t a = ok ? row[w0] : 0u, b = (ok && w1 != w0) ? row[w1] : 0u;
+            const uint32_t below = (1u << (x0 & 31)) - 1u;                                        // bits under x0
+            const uint32_t upto = (x1 & 31) == 31 ? 0xffffffffu : ((1u << ((x1 & 31) + 1)) - 1u);  // bits up to x1
+            acc |= w1 == w0 ? (a & upto & ~below) : ((a & ~below) | (b & upto));
+        }
+        return acc != 0u;
+    }
     bool hit = false;
     for (int y = pi - R; y <= pi + R; y++) {
         if (y < 0 || y >= CAGYM_MAPD) continue;

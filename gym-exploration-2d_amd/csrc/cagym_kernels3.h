@@ -163,6 +163,7 @@ struct Lds3 {
     int* wnob;     // [32] rectangles of that scenario
     float4* rect;  // [worlds x Kobs x 4] the worlds' prepared rectangles (OBST only), staged at episode start
     uint16_t* blist;  // [waves x 256] (OBST only) a wave's list of the laser beams that can meet a rectangle
+    uint32_t* cov;    // [ko][AS] (OBST only) obstacle_lines_phase3's coverage bit matrix
     int* flag;     // [8]  0: a world was reset this step   1: OAS row chunks claimed   2: LP waves finished
                    //      3/4: some ego needed linearProgram3 this / the previous step
     float2* lpv;   // [AS] preferred (optimisation) velocity of each ego
@@ -188,7 +189,7 @@ __host__ __device__ inline size_t cagym_lds3_bytes(int M, int AS, int NT, int ko
     const size_t MP = cagym_mp(M);
     return a16(cagym_lds3_head(AS)) + a16(AS * MP * 4) + (size_t)(ko + M - 1) * AS * 16 + (size_t)lpl * NT * 16 + 2 * AS * MP * 8 + a16(AS * MP) +
            (size_t)(AS / M) * (ko / 2) * 64 +  // staged rectangles: worlds x Kobs x 4 float4
-           (lpl == 4 ? (size_t)(NT / CAGYM_WAVE) * 512 : 0);  // OBST: per-wave beam lists
+           (lpl == 4 ? (size_t)(NT / CAGYM_WAVE) * 512 + (size_t)ko * AS * 4 : 0);  // OBST: per-wave beam lists, coverage bits
 }
 
 __device__ __forceinline__ Lds3 carve_lds3(unsigned char* smem, int M, int AS, int NT, int ko = 0, int lpl = 2) {
@@ -227,6 +228,7 @@ __device__ __forceinline__ Lds3 carve_lds3(unsigned char* smem, int M, int AS, i
     W.hit = reinterpret_cast<uint8_t*>(W.gap + AS * MP);
     W.rect = reinterpret_cast<float4*>(reinterpret_cast<unsigned char*>(W.hit) + a16(AS * MP));
     W.blist = reinterpret_cast<uint16_t*>(reinterpret_cast<unsigned char*>(W.rect) + (size_t)(AS / M) * (ko / 2) * 64);
+    W.cov = reinterpret_cast<uint32_t*>(W.blist + (size_t)(NT / CAGYM_WAVE) * 256);
     return W;
 }
 
@@ -305,19 +307,30 @@ __device__ __forceinline__ void publish_pref_velocity3(const Lds3& W, int a) {
 }
 
 // Obstacle half-planes of every live RVO ego of the workgroup (RVOPolicy.py:56-57; the obstacle half of
-// Agent::computeNewVelocity), on all lanes in four sub-steps: (1) one lane per (ego, rectangle) tests the four edges and
-// appends the neighbours to the ego's candidate list (LDS counter); (2) one lane per ego sorts its candidates by (squared
-// distance, rectangle, edge) - the order Agent::insertObstacleNeighbor's insertion sort produces; (3) one lane per (ego,
-// candidate) builds the candidate's half-plane (it does not depend on the earlier ones); (4) one lane per ego walks its
-// candidates in order, drops those already covered by a kept line, compacts the kept lines to rows 0 .. nobl-1 of its column
-// and tests them against the LP start.  Needs: W.rect staged, W.lpc published, W.nobl zero, a barrier behind all three; every
-// thread of the workgroup calls it (three barriers inside); the caller's next barrier publishes the result.
+// Agent::computeNewVelocity), on all lanes in five sub-steps: (1) one lane per (ego, rectangle) tests the four edges and
+// appends the neighbours to the ego's candidate list (LDS counter); (2) one lane per ego turns its count into a share of the
+// workgroup's dense (ego, candidate) work list; (3) one lane per (ego, candidate) finds the candidate's rank by counting -
+// (squared distance, rectangle, edge) is the order Agent::insertObstacleNeighbor's insertion sort produces - and builds its
+// half-plane (it does not depend on the earlier ones) into row `rank`; (4) one lane per (ego, candidate, earlier candidate)
+// evaluates "already covered by that line" into a bit matrix; (5) one lane per ego walks its candidates in order: a candidate
+// covered by a KEPT line is dropped (bit tests), the kept lines are compacted to rows 0 .. nobl-1 of its column and tested
+// against the LP start.  Sub-steps 2 and 5 used to be an insertion sort and a nested loop per ego lane (27 000 of the phase's
+// 38 000 cycles).  Needs: W.rect staged, W.lpc published, W.nobl zero, a barrier behind all three; every thread of the
+// workgroup calls it (four barriers inside); the caller's next barrier publishes the result.  ko <= 32 (bit masks).
 __device__ inline void obstacle_lines_phase3(const CagymDev& D, const Lds3& W, int M, int AS, int ko, int nagents, uint32_t inv_m) {
     const int tid = threadIdx.x, NTT = blockDim.x, Kobs = D.Kobs;
-    float2* nbr = reinterpret_cast<float2*>(W.lp3);  // [ko][AS] candidates (squared distance, id) in the idle LP3 scratch
-    int* todo = reinterpret_cast<int*>(nbr + ko * AS);  // [<= nagents * ko] (ego << 8 | candidate) behind them
+    float2* nbr = reinterpret_cast<float2*>(W.lp3);      // [ko][AS] candidates (squared distance, id) in the idle LP3 scratch
+    int* todo = reinterpret_cast<int*>(nbr + ko * AS);   // [<= nagents * ko] (ego << 8 | candidate, later rank) behind them
+    uint8_t* perm = reinterpret_cast<uint8_t*>(todo + ko * AS);  // [ko][AS] candidate at each rank
+    uint32_t* cov = W.cov;                               // [ko][AS] bit s of entry (rank r, ego): line s covers candidate r
     const float inv_tho = 1.0f / 5.0f;
-    if (tid == 0) W.flag[5] = 0;  // the barrier behind sub-step 1 publishes it
+#ifdef CAGYM_STAMPS  // sub-step shares (slots 0, 9, 10, 11; they are part of phase A's slot as well)
+    unsigned long long ob_prev = __builtin_amdgcn_s_memtime();
+#define OBSTAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) { unsigned long long _t = __builtin_amdgcn_s_memtime(); g_stamps[i] += _t - ob_prev; ob_prev = _t; } } while (0)
+#else
+#define OBSTAMP(i) do { } while (0)
+#endif
+    if (tid == 0) { W.flag[5] = 0; W.flag[6] = 0; }  // the barrier behind sub-step 1 publishes them
     for (int q = tid; q < nagents * Kobs; q += NTT) {
         const int a = q / Kobs, r = q - a * Kobs;
         if (!W.trvo[a]) continue;
@@ -336,61 +349,77 @@ __device__ inline void obstacle_lines_phase3(const CagymDev& D, const Lds3& W, i
         }
     }
     __syncthreads();
+    OBSTAMP(0);
     if (tid >= NTT - CAGYM_WAVE) {
         const int a = tid - (NTT - CAGYM_WAVE);
         if (a < nagents) {
             int n = W.nobl[a];
             n = n < ko ? n : ko;
-            for (int i = 1; i < n; i++) {  // insertion sort by (squared distance, id): n <= 2 per rectangle in range
-                const float2 c = nbr[i * AS + a];
-                int j = i;
-                while (j > 0) {
-                    const float2 p = nbr[(j - 1) * AS + a];
-                    if (!(c.x < p.x || (c.x == p.x && __float_as_int(c.y) < __float_as_int(p.y)))) break;
-                    nbr[j * AS + a] = p;
-                    j--;
-                }
-                nbr[j * AS + a] = c;
-            }
             W.nobl[a] = n;
-            // the (ego, candidate) pairs of the whole workgroup as one dense list: sub-step 3 is one round of lanes
-            const int base = n > 0 ? __hip_atomic_fetch_add(&W.flag[5], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0;
-            for (int i = 0; i < n; i++) todo[base + i] = (a << 8) | i;
+            if (n > 0) {
+                // the (ego, candidate) pairs of the whole workgroup as one dense list: the next sub-steps are rounds of full waves
+                const int base = __hip_atomic_fetch_add(&W.flag[5], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_max(&W.flag[6], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                for (int i = 0; i < n; i++) todo[base + i] = (a << 8) | i;
+            }
         }
     }
     __syncthreads();
-    const int ntodo = W.flag[5];
+    OBSTAMP(9);
+    const int ntodo = W.flag[5], nmax = W.flag[6];
     for (int q = tid; q < ntodo; q += NTT) {
         const int a = todo[q] >> 8, i = todo[q] & 255;
+        const int n = W.nobl[a];
+        const float2 me = nbr[i * AS + a];
+        int rank = 0;  // candidates before this one: smaller (squared distance, id)
+        for (int l = 0; l < n; l++) {
+            const float2 o = nbr[l * AS + a];
+            rank += (o.x < me.x) || (o.x == me.x && __float_as_int(o.y) < __float_as_int(me.y));
+        }
         const int wl = (int)__umulhi((uint32_t)a, inv_m);
         const float px = (float)W.tpx[a], py = (float)W.tpy[a], vx = (float)W.tvx[a], vy = (float)W.tvy[a];
         const float radius = (float)((1 + 15e-2) * W.tr[a]);
         float4 ln;
-        const bool ok = orca_obstacle_line_of(W.rect + wl * Kobs * 4, __float_as_int(nbr[i * AS + a].y), px, py, vx, vy, radius, inv_tho, ln);
+        const bool ok = orca_obstacle_line_of(W.rect + wl * Kobs * 4, __float_as_int(me.y), px, py, vx, vy, radius, inv_tho, ln);
         if (!ok) ln.z = __int_as_float(0x7fc00000);  // "this edge contributes no half-plane": NaN direction
-        W.sorted[i * AS + a] = ln;
+        W.sorted[rank * AS + a] = ln;
+        perm[rank * AS + a] = (uint8_t)i;
+        cov[rank * AS + a] = 0u;
+        todo[q] = (a << 8) | rank;  // (only this lane reads or writes entry q)
     }
     __syncthreads();
+    OBSTAMP(10);
+    for (int w = tid; w < ntodo * nmax; w += NTT) {
+        const int q = w / nmax, sidx = w - q * nmax;
+        const int a = todo[q] >> 8, r = todo[q] & 255;
+        if (sidx >= r) continue;
+        const float4 ls = W.sorted[sidx * AS + a];
+        if (ls.z != ls.z) continue;  // no half-plane at that rank: never kept, covers nothing
+        const int wl = (int)__umulhi((uint32_t)a, inv_m);
+        const int id = __float_as_int(nbr[perm[r * AS + a] * AS + a].y);
+        const float px = (float)W.tpx[a], py = (float)W.tpy[a];
+        const float radius = (float)((1 + 15e-2) * W.tr[a]);
+        if (orca_edge_covered_by(W.rect + wl * Kobs * 4, id, px, py, radius, inv_tho, ls))
+            __hip_atomic_fetch_or(&cov[r * AS + a], 1u << sidx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __syncthreads();
+    OBSTAMP(11);
     if (tid >= NTT - CAGYM_WAVE) {
         const int a = tid - (NTT - CAGYM_WAVE);
         if (a < nagents) {
             const int n = W.nobl[a];
             int nl = 0;
             if (n > 0) {
-                const int wl = (int)__umulhi((uint32_t)a, inv_m);
-                const float px = (float)W.tpx[a], py = (float)W.tpy[a];
-                const float radius = (float)((1 + 15e-2) * W.tr[a]);
                 const float2 s0 = W.lpc[a];
                 bool viol = false;
-                for (int i = 0; i < n; i++) {
-                    const int id = __float_as_int(nbr[i * AS + a].y);
-                    bool covered = false;
-                    for (int j = 0; j < nl; j++) covered |= orca_edge_covered_by(W.rect + wl * Kobs * 4, id, px, py, radius, inv_tho, W.sorted[j * AS + a]);
-                    if (covered) continue;
-                    const float4 ln = W.sorted[i * AS + a];
-                    if (ln.z != ln.z) continue;  // no half-plane from this edge
-                    W.sorted[nl * AS + a] = ln;   // nl <= i: in place
+                uint32_t kept = 0u;  // ranks whose line was kept
+                for (int r = 0; r < n; r++) {
+                    if (cov[r * AS + a] & kept) continue;  // already covered by a kept line
+                    const float4 ln = W.sorted[r * AS + a];
+                    if (ln.z != ln.z) continue;   // no half-plane from this edge
+                    W.sorted[nl * AS + a] = ln;   // nl <= r: in place
                     nl++;
+                    kept |= 1u << r;
                     viol |= detf(ln.z, ln.w, ln.x - s0.x, ln.y - s0.y) > 0.0f;
                 }
                 if (viol) W.busy[a] = 1;
@@ -398,7 +427,7 @@ __device__ inline void obstacle_lines_phase3(const CagymDev& D, const Lds3& W, i
             W.nobl[a] = nl;
         }
     }
-}  // (W.flag[5] is read before the third barrier and reset behind the caller's barrier at the next call)
+}  // (W.flag[5], W.flag[6] are read before the third barrier and reset behind the caller's barrier at the next call)
 
 // What of the next ORCA solve depends on ego a alone: preferred velocity / LP start (the obstacle half-planes of worlds with
 // rectangles follow in obstacle_lines_phase3, which counts on nobl = 0).
