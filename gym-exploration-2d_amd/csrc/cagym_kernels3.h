@@ -1025,8 +1025,10 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
                     }
                     const bool coll_agent = hits != 0;
                     if (OBST && D.map_bits) {
-                        int sidx = (int)(((long long)C.world + (long long)C.episode * D.N) % D.S);
-                        if (D.sc_nobst[sidx] > 0)
+                        // scenario index and (with staged rectangles) rectangle count from LDS: no 64-bit modulo, no dependent global load
+                        const int sidx = W.wsc[C.wl];
+                        const int nrect = ko > 0 ? W.wnob[C.wl] : D.sc_nobst[sidx];
+                        if (nrect > 0)
                             coll_wall = wall_collision(D.map_bits + (size_t)sidx * CAGYM_MAPD * CAGYM_MAPW, S.px, S.py, S.r);
                     }
                     double r = -0.01;
