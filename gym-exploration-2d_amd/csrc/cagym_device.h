@@ -375,3 +375,46 @@ __device__ __forceinline__ bool wall_collision(const uint32_t* map, double px, d
     }
     return hit;
 }
+
+// The same test split for the step kernels (wall_flags3): the per-agent part - cell, window, the half-width of every row
+// distance |dy| <= 8 (4 bits each, 15 = no cell of that row in the disk) - is computed once per agent, the per-row part (one or
+// two raster words against the span) on a lane per (agent, row).  wall_collision == OR over the 17 rows.  flags bit 0: the
+// agent's cell is in the map and its window fits (R <= 8); bit 1: too large for the window (radius > 0.7 m): tested whole.
+struct WallPrep {
+    int cell;              // pi | pj << 16
+    int flags;
+    unsigned long long w;  // half-widths of |dy| = 0 .. 8
+};
+__device__ __forceinline__ WallPrep wall_prep(double px, double py, double radius) {
+    int pi, pj;
+    const bool in = world_to_cell(px, py, pi, pj);
+    const double rr = radius / 0.1, r2 = rr * rr;
+    const int R = (int)ceil(rr) + 1;
+    WallPrep o;
+    o.cell = in ? (pi | (pj << 16)) : 0;
+    o.flags = (in && R <= 8 ? 1 : 0) | (in && R > 8 ? 2 : 0);
+    unsigned long long packed = 0ull;
+    int w = R > 8 ? -1 : R;
+#pragma unroll
+    for (int dy = 0; dy <= 8; dy++) {
+        if (dy > R) w = -1;
+        while (w >= 0 && !((double)w * (double)w + (double)dy * (double)dy < r2)) w--;
+        packed |= (unsigned long long)(w < 0 ? 15 : w) << (4 * dy);
+    }
+    o.w = packed;
+    return o;
+}
+__device__ __forceinline__ bool wall_row_hit(const uint32_t* map, int cell, int flags, unsigned long long widths, int k) {
+    const int pi = cell & 0xffff, pj = cell >> 16, ady = k < 0 ? -k : k, y = pi + k;
+    const int w = (int)((widths >> (4 * ady)) & 15ull);
+    const bool ok = (flags & 1) && w != 15 && y >= 0 && y < CAGYM_MAPD;
+    int x0 = ok ? pj - w : 0, x1 = ok ? pj + w : 0;
+    x0 = x0 < 0 ? 0 : x0;
+    x1 = x1 >= CAGYM_MAPD ? CAGYM_MAPD - 1 : x1;
+    const int w0 = x0 >> 5, w1 = x1 >> 5;
+    const uint32_t* row = map + (ok ? y : 0) * CAGYM_MAPW;
+    const uint32_t a = row[w0], b = row[w1];  // unconditional (clamped) loads: no branch around them
+    const uint32_t below = (1u << (x0 & 31)) - 1u;
+    const uint32_t upto = (x1 & 31) == 31 ? 0xffffffffu : ((1u << ((x1 & 31) + 1)) - 1u);
+    return ok && (w1 == w0 ? (a & upto & ~below) : ((a & ~below) | (b & upto))) != 0u;
+}

@@ -164,6 +164,7 @@ struct Lds3 {
     float4* rect;  // [worlds x Kobs x 4] the worlds' prepared rectangles (OBST only), staged at episode start
     uint16_t* blist;  // [waves x 256] (OBST only) a wave's list of the laser beams that can meet a rectangle
     uint32_t* cov;    // [ko][AS] (OBST only) obstacle_lines_phase3's coverage bit matrix
+    int* wall;        // [4 AS] (OBST only) wall_prep3's per-agent cell / window / row half-widths
     int* flag;     // [8]  0: a world was reset this step   1: OAS row chunks claimed   2: LP waves finished
                    //      3/4: some ego needed linearProgram3 this / the previous step
     float2* lpv;   // [AS] preferred (optimisation) velocity of each ego
@@ -189,7 +190,7 @@ __host__ __device__ inline size_t cagym_lds3_bytes(int M, int AS, int NT, int ko
     const size_t MP = cagym_mp(M);
     return a16(cagym_lds3_head(AS)) + a16(AS * MP * 4) + (size_t)(ko + M - 1) * AS * 16 + (size_t)lpl * NT * 16 + 2 * AS * MP * 8 + a16(AS * MP) +
            (size_t)(AS / M) * (ko / 2) * 64 +  // staged rectangles: worlds x Kobs x 4 float4
-           (lpl == 4 ? (size_t)(NT / CAGYM_WAVE) * 512 + (size_t)ko * AS * 4 : 0);  // OBST: per-wave beam lists, coverage bits
+           (lpl == 4 ? (size_t)(NT / CAGYM_WAVE) * 512 + a16((size_t)ko * AS * 4) + (size_t)AS * 16 : 0);  // OBST: beam lists, coverage bits, wall prep
 }
 
 __device__ __forceinline__ Lds3 carve_lds3(unsigned char* smem, int M, int AS, int NT, int ko = 0, int lpl = 2) {
@@ -229,6 +230,7 @@ __device__ __forceinline__ Lds3 carve_lds3(unsigned char* smem, int M, int AS, i
     W.rect = reinterpret_cast<float4*>(reinterpret_cast<unsigned char*>(W.hit) + a16(AS * MP));
     W.blist = reinterpret_cast<uint16_t*>(reinterpret_cast<unsigned char*>(W.rect) + (size_t)(AS / M) * (ko / 2) * 64);
     W.cov = reinterpret_cast<uint32_t*>(W.blist + (size_t)(NT / CAGYM_WAVE) * 256);
+    W.wall = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(W.cov) + a16((size_t)ko * AS * 4));
     return W;
 }
 
@@ -306,6 +308,43 @@ __device__ __forceinline__ void publish_pref_velocity3(const Lds3& W, int a) {
     W.busy[a] = 0;
 }
 
+// Wall test (env.py:656-666) of every agent slot of the workgroup in two parts.  wall_prep3: one lane per agent computes the
+// cell, the window and the rows' half-widths into W.wall (4 ints per agent).  wall_rows3 (behind a barrier): a wave round
+// takes 3 agents x 17 raster rows, a ballot folds the rows, the result waits in W.lpk (idle between two LP phases) for S2.
+// On wave 0 alone, inside S2, the test was 15 000 of the step's 78 000 cycles with the other waves idle; with the per-agent
+// part repeated on every row lane it was no faster.
+__device__ __forceinline__ void wall_prep3(const CagymDev& D, const Lds3& W, int a, int ko, uint32_t inv_m, int M) {
+    const int wl = (int)__umulhi((uint32_t)a, inv_m);
+    const int nrect = ko > 0 ? W.wnob[wl] : D.sc_nobst[W.wsc[wl]];
+    WallPrep P = {0, 0, 0ull};
+    if ((a - wl * M) < W.wn[wl] && nrect > 0) P = wall_prep(W.tpx[a], W.tpy[a], W.tr[a]);
+    reinterpret_cast<int4*>(W.wall)[a] = make_int4(P.cell, P.flags, (int)(P.w & 0xffffffffull), (int)(P.w >> 32));
+}
+template <int NWAVES>
+__device__ __forceinline__ void wall_rows3(const CagymDev& D, const Lds3& W, int nagents, uint32_t inv_m) {
+    constexpr int ROUNDS = (22 + NWAVES - 1) / NWAVES;  // <= 64 agent slots = 22 groups of 3
+    const int lane = threadIdx.x & (CAGYM_WAVE - 1), wave = threadIdx.x / CAGYM_WAVE;
+    const int sub = lane / 17, k = lane - sub * 17 - 8;  // lanes 51 .. 63 idle
+#pragma unroll
+    for (int r = 0; r < ROUNDS; r++) {
+        const int g = wave + r * NWAVES;
+        if (g * 3 >= nagents) break;  // wave-uniform
+        const int a = g * 3 + sub;
+        const bool slot_ok = sub < 3 && a < nagents;
+        const int ac = slot_ok ? a : 0;
+        const int4 P = reinterpret_cast<const int4*>(W.wall)[ac];
+        const int wl = (int)__umulhi((uint32_t)ac, inv_m);
+        const uint32_t* map = D.map_bits + (size_t)W.wsc[wl] * CAGYM_MAPD * CAGYM_MAPW;
+        const bool hit_row = wall_row_hit(map, P.x, slot_ok ? P.y : 0, ((unsigned long long)(uint32_t)P.w << 32) | (uint32_t)P.z, k);
+        const unsigned long long m = __ballot(hit_row);
+        if (slot_ok && k == -8) {
+            bool hit = ((m >> (sub * 17)) & 0x1ffffull) != 0ull;
+            if (P.y & 2) hit = wall_collision(map, W.tpx[a], W.tpy[a], W.tr[a]);  // radius > 0.7 m: the whole test on this lane (rare)
+            W.lpk[a] = hit ? 1 : 0;
+        }
+    }
+}
+
 // Obstacle half-planes of every live RVO ego of the workgroup (RVOPolicy.py:56-57; the obstacle half of
 // Agent::computeNewVelocity), on all lanes in five sub-steps: (1) one lane per (ego, rectangle) tests the four edges and
 // appends the neighbours to the ego's candidate list (LDS counter); (2) one lane per ego turns its count into a share of the
@@ -330,7 +369,6 @@ __device__ inline void obstacle_lines_phase3(const CagymDev& D, const Lds3& W, i
 #else
 #define OBSTAMP(i) do { } while (0)
 #endif
-    if (tid == 0) { W.flag[5] = 0; W.flag[6] = 0; }  // the barrier behind sub-step 1 publishes them
     for (int q = tid; q < nagents * Kobs; q += NTT) {
         const int a = q / Kobs, r = q - a * Kobs;
         if (!W.trvo[a]) continue;
@@ -351,18 +389,25 @@ __device__ inline void obstacle_lines_phase3(const CagymDev& D, const Lds3& W, i
     __syncthreads();
     OBSTAMP(0);
     if (tid >= NTT - CAGYM_WAVE) {
+        // the (ego, candidate) pairs of the whole workgroup as one dense list (the next sub-steps are rounds of full waves): every ego
+        // is a lane of this wave, so its share is a prefix sum (50 lanes adding to one LDS counter cost 4 000 cycles)
         const int a = tid - (NTT - CAGYM_WAVE);
+        int n = 0;
         if (a < nagents) {
-            int n = W.nobl[a];
+            n = W.nobl[a];
             n = n < ko ? n : ko;
             W.nobl[a] = n;
-            if (n > 0) {
-                // the (ego, candidate) pairs of the whole workgroup as one dense list: the next sub-steps are rounds of full waves
-                const int base = __hip_atomic_fetch_add(&W.flag[5], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_max(&W.flag[6], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                for (int i = 0; i < n; i++) todo[base + i] = (a << 8) | i;
-            }
         }
+        int incl = n, mx = n;
+        for (int off = 1; off < CAGYM_WAVE; off <<= 1) {
+            const int v = __shfl_up(incl, off);
+            if (a >= off) incl += v;
+            const int u = __shfl_xor(mx, off);
+            mx = u > mx ? u : mx;
+        }
+        const int base = incl - n;
+        for (int i = 0; i < n; i++) todo[base + i] = (a << 8) | i;
+        if (a == CAGYM_WAVE - 1) { W.flag[5] = incl; W.flag[6] = mx; }
     }
     __syncthreads();
     OBSTAMP(9);
@@ -427,7 +472,7 @@ __device__ inline void obstacle_lines_phase3(const CagymDev& D, const Lds3& W, i
             W.nobl[a] = nl;
         }
     }
-}  // (W.flag[5], W.flag[6] are read before the third barrier and reset behind the caller's barrier at the next call)
+}
 
 // What of the next ORCA solve depends on ego a alone: preferred velocity / LP start (the obstacle half-planes of worlds with
 // rectangles follow in obstacle_lines_phase3, which counts on nobl = 0).
@@ -993,12 +1038,13 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
             if (a < nagents && any_rvo && t + 1 < n_steps) ego_lp_inputs3<OBST>(D, W, a, M, AS, ko, inv_m);
             WAVETRACE(t, 7);
         }
+        if (OBST && D.map_bits && agent_lane) wall_prep3(D, W, tid, ko, inv_m, M);  // wave 0, beside the last wave's LP inputs
         for (int p = tid; p < nup; p += NT) pair_distances3<MT>(D, W, p, M, MP);
         WAVETRACE(t, 8);
-        if (OBST && ko > 0 && any_rvo && t + 1 < n_steps) {
-            __syncthreads();
-            obstacle_lines_phase3(D, W, M, AS, ko, nagents, inv_m);
-        }
+        const bool obst_lines = OBST && ko > 0 && any_rvo && t + 1 < n_steps;
+        if (OBST && (D.map_bits || obst_lines)) __syncthreads();
+        if (OBST && D.map_bits) wall_rows3<NWAVES>(D, W, nagents, inv_m);
+        if (obst_lines) obstacle_lines_phase3(D, W, M, AS, ko, nagents, inv_m);
         __syncthreads();
         STAMP(5);
         WAVETRACE(t, 9);
@@ -1024,13 +1070,7 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
                         dmin = fmin(dmin, fmin(fmin(g0.x, g0.y), fmin(g1.x, g1.y)));
                     }
                     const bool coll_agent = hits != 0;
-                    if (OBST && D.map_bits) {
-                        // scenario index and (with staged rectangles) rectangle count from LDS: no 64-bit modulo, no dependent global load
-                        const int sidx = W.wsc[C.wl];
-                        const int nrect = ko > 0 ? W.wnob[C.wl] : D.sc_nobst[sidx];
-                        if (nrect > 0)
-                            coll_wall = wall_collision(D.map_bits + (size_t)sidx * CAGYM_MAPD * CAGYM_MAPW, S.px, S.py, S.r);
-                    }
+                    if (OBST && D.map_bits) coll_wall = W.lpk[tid] != 0;  // wall_flags3 in phase A
                     double r = -0.01;
                     if (S.st & CAGYM_FLAG_AT_GOAL) {
                         if (!(S.st & CAGYM_FLAG_WAS_AT_GOAL)) r = 3.0;

@@ -18,8 +18,13 @@ if "--child" not in sys.argv:
 scen = importlib.import_module("gym-exploration-2d_amd.scenarios")
 B = importlib.import_module("gym-exploration-2d_amd.batched_env").BatchedCollisionAvoidanceEnv
 N, M, T = int(os.environ.get("LC_WORLDS", 4096)), 10, 24
-env = B(N, M, n_scenarios=8 * N, game_over_mode="all")
-env.set_scenarios(scen.random_worlds_fast(8 * N, M, seed=1234), scen.POLICY_RVO, scen.DYN_UNICYCLE, coop=np.full((8 * N, M), 0.5))
+if os.environ.get("LC_OBST"):  # cfg4's env part as a roll-out: RVO agents among 2-10 rectangles (OBST instantiation)
+    a6, ob, nob, _ = scen.obstacle_worlds(2 * N, M, 10, seed=3)
+    env = B(N, M, n_scenarios=2 * N, max_obstacles=10, game_over_mode="all", laserscan=bool(os.environ.get("LC_LASER")))
+    env.set_scenarios(a6, scen.POLICY_RVO, scen.DYN_UNICYCLE, coop=np.full((2 * N, M), 0.5), obstacles=ob, n_obst=nob)
+else:
+    env = B(N, M, n_scenarios=8 * N, game_over_mode="all")
+    env.set_scenarios(scen.random_worlds_fast(8 * N, M, seed=1234), scen.POLICY_RVO, scen.DYN_UNICYCLE, coop=np.full((8 * N, M), 0.5))
 env.reset()
 traj = env.alloc_rollout(64)
 for _ in range(6):
