@@ -259,11 +259,7 @@ __device__ __forceinline__ bool take_action(Agent& A, float act0, float act1, do
             need_trig = false;
         }
     }
-#ifdef CAGYM_EXPERIMENT_NOTRIG
-    if (need_trig) { c = 1.0; s = 0.0; }
-#else
     if (need_trig) sincos(hn, &s, &c);
-#endif
     double dx = speed * c * dt, dy = speed * s * dt;
     A.px += dx;
     A.py += dy;
@@ -376,7 +372,7 @@ __device__ __forceinline__ bool wall_collision(const uint32_t* map, double px, d
     return hit;
 }
 
-// The same test split for the step kernels (wall_flags3): the per-agent part - cell, window, the half-width of every row
+// The same test split for the step kernels (wall_prep3 / wall_rows3): the per-agent part - cell, window, the half-width of every row
 // distance |dy| <= 8 (4 bits each, 15 = no cell of that row in the disk) - is computed once per agent, the per-row part (one or
 // two raster words against the span) on a lane per (agent, row).  wall_collision == OR over the 17 rows.  flags bit 0: the
 // agent's cell is in the map and its window fits (R <= 8); bit 1: too large for the window (radius > 0.7 m): tested whole.

@@ -1070,7 +1070,7 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
                         dmin = fmin(dmin, fmin(fmin(g0.x, g0.y), fmin(g1.x, g1.y)));
                     }
                     const bool coll_agent = hits != 0;
-                    if (OBST && D.map_bits) coll_wall = W.lpk[tid] != 0;  // wall_flags3 in phase A
+                    if (OBST && D.map_bits) coll_wall = W.lpk[tid] != 0;  // wall_prep3 / wall_rows3 in phase A
                     double r = -0.01;
                     if (S.st & CAGYM_FLAG_AT_GOAL) {
                         if (!(S.st & CAGYM_FLAG_WAS_AT_GOAL)) r = 3.0;

@@ -679,50 +679,6 @@ __device__ __forceinline__ bool orca_edge_covered_by(const float4* rects, int id
            detf(inv_tho * rp2x - lj.x, inv_tho * rp2y - lj.y, lj.z, lj.w) - inv_tho * radius >= -RVO_EPS;
 }
 
-// Obstacle neighbours (nearest first) of one ego and their ORCA lines, written to L[k * stride], k < return value <= cap.
-// nbr: private scratch of the lane, `cap` entries (key = squared distance, id = 4 * rectangle + edge) at nbr_stride.
-// One lane per ego; every loop is bounded by 4 * n_obst.
-__device__ inline int orca_obstacle_lines(const float4* rects, int n_obst, float px, float py, float vx, float vy, float radius,
-                                          float max_speed, float time_horizon_obst, float4* L, int stride, int cap,
-                                          float2* nbr, int nbr_stride) {
-    const float range = time_horizon_obst * max_speed + radius, range_sq = range * range;
-    int nn = 0;
-    for (int r = 0; r < n_obst; r++) {
-        for (int k = 0; k < 4; k++) {
-            const OrcaVertex o1 = orca_rect_vertex(rects + 4 * r, k), o2 = orca_rect_vertex(rects + 4 * r, (k + 1) & 3);
-            const float left = detf(o1.x - px, o1.y - py, o2.x - o1.x, o2.y - o1.y);  // leftOf(o1, o2, position)
-            if (!(left < 0.0f)) continue;  // only from its right side (the agent can see it); half of the edges end here
-            const float ex = o2.x - o1.x, ey = o2.y - o1.y;
-            const float dsq_line = (left * left) / (ex * ex + ey * ey);
-            if (!(dsq_line < range_sq) || !(left < 0.0f)) continue;  // only from its right side (the agent can see it)
-            const float dsq = orca_dist_sq_point_segment(o1.x, o1.y, o2.x, o2.y, px, py);
-            if (!(dsq < range_sq)) continue;
-            if (nn >= cap) continue;  // cannot happen for an agent outside every rectangle (<= 2 visible edges each)
-            int i = nn++;  // Agent::insertObstacleNeighbor: insertion sort, strict <
-            while (i != 0 && dsq < nbr[(i - 1) * nbr_stride].x) {
-                nbr[i * nbr_stride] = nbr[(i - 1) * nbr_stride];
-                i--;
-            }
-            nbr[i * nbr_stride] = make_float2(dsq, __int_as_float(4 * r + k));
-        }
-    }
-    const float inv_tho = 1.0f / time_horizon_obst;
-    int nl = 0;
-    for (int q = 0; q < nn; q++) {
-        const int id = __float_as_int(nbr[q * nbr_stride].y);
-        const int r = id >> 2, k = id & 3;
-        const OrcaVertex o1 = orca_rect_vertex(rects + 4 * r, k), o2 = orca_rect_vertex(rects + 4 * r, (k + 1) & 3),
-                         pv = orca_rect_vertex(rects + 4 * r, (k + 3) & 3);
-        float4 ln;
-        if (orca_obstacle_line(o1, o2, pv, px, py, vx, vy, radius, inv_tho, L, stride, nl, ln)) {
-            L[nl * stride] = ln;
-            nl++;
-        }
-    }
-    return nl;
-}
-
-
 // ---- linearProgram2/3 on a GW-lane group with LPL half-planes per lane and protected obstacle lines ----------------------
 // Line q of the solve (q < no: obstacle line q, row q of the ego's column; q >= no: agent line q - no, row ko + q - no)
 // lives on lane q % GW, slot q / GW.  linearProgram3 keeps the obstacle lines as they are and projects only the agent
