@@ -930,8 +930,12 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
                     const float rad = W.lpr[a];
                     float vx, vy;
                     if (OBST) {
-                        orca_lp_group_n<GW, LPL>(W.sorted, W.lp3 + LPL * (tid & ~(GW - 1)), a, j, W.nobl[a], nn, ko, rad, pv.x, pv.y,
-                                                 vx, vy, AS, &W.flag[3]);
+                        // two half-planes per lane serve 2 GW lines; only a wave that holds an ego with more runs the 4-per-lane code
+                        const int nol = W.nobl[a];
+                        if (__ballot(nol + nn > 2 * GW) != 0ull)
+                            orca_lp_group_n<GW, LPL>(W.sorted, W.lp3 + LPL * (tid & ~(GW - 1)), a, j, nol, nn, ko, rad, pv.x, pv.y, vx, vy, AS, &W.flag[3]);
+                        else
+                            orca_lp_group_n<GW, 2>(W.sorted, W.lp3 + LPL * (tid & ~(GW - 1)), a, j, nol, nn, ko, rad, pv.x, pv.y, vx, vy, AS, &W.flag[3]);
                     } else {
 #ifdef CAGYM_STAMPS
                         orca_lp_group<GW, TWO, (MT > 0 ? MT - 1 : 0)>(W.sorted, W.lp3 + 2 * (tid & ~(GW - 1)), a, j, nn, rad, pv.x, pv.y, vx, vy, AS, &W.flag[3], dbg);
