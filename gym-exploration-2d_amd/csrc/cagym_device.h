@@ -391,10 +391,12 @@ __device__ __forceinline__ WallPrep wall_prep(double px, double py, double radiu
     o.flags = (in && R <= 8 ? 1 : 0) | (in && R > 8 ? 2 : 0);
     unsigned long long packed = 0ull;
     int w = R > 8 ? -1 : R;
+    // w^2 + dy^2 < r2 for integers <=> w^2 + dy^2 <= ceil(r2) - 1: the sweep runs on integers (r2 <= 49 here)
+    const int lim = R > 8 ? -1 : (int)ceil(r2) - 1;
 #pragma unroll
     for (int dy = 0; dy <= 8; dy++) {
         if (dy > R) w = -1;
-        while (w >= 0 && !((double)w * (double)w + (double)dy * (double)dy < r2)) w--;
+        while (w >= 0 && w * w + dy * dy > lim) w--;
         packed |= (unsigned long long)(w < 0 ? 15 : w) << (4 * dy);
     }
     o.w = packed;
