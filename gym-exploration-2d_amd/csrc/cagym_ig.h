@@ -37,7 +37,16 @@ __device__ __forceinline__ void mat2vec(double c, double s, double vx, double vy
 
 // edfMap.get_edf_value_from_pose (edfMap.py:14-19)
 __device__ __forceinline__ double edf_at(const uint32_t* d2, double x, double y) {
-    double fx = floor((x + IG_HALF) / IG_EDF_CELL), fy = floor((y + IG_HALF) / IG_EDF_CELL);
+    // floor((x + 15) / 0.1): the product with 10.0 differs from the correctly rounded quotient by a few ulp, so the floors agree
+    // unless the product is within 1e-7 of an integer - then (and for huge / NaN operands) the division decides.  The two
+    // divisions were 50 of the ~135 instructions of a trace step, and the traces are arithmetic-bound.
+    const double tx = x + IG_HALF, ty = y + IG_HALF;
+    double qx = tx * 10.0, qy = ty * 10.0;
+    if (!(fabs(qx - rint(qx)) > 1e-7 && fabs(qy - rint(qy)) > 1e-7 && fabs(qx) < 1e6 && fabs(qy) < 1e6)) {
+        qx = tx / IG_EDF_CELL;
+        qy = ty / IG_EDF_CELL;
+    }
+    double fx = floor(qx), fy = floor(qy);
     if (!(fx > -1e6 && fx < 1e6 && fy > -1e6 && fy < 1e6)) return 0.0;
     int xi = (int)fx, yi = (int)fy;
     if (xi < 0) xi += CAGYM_MAPD;
@@ -61,7 +70,7 @@ __device__ inline bool ig_check_visibility(const uint32_t* d2, double px, double
 }
 
 __device__ __forceinline__ int ig_bel_cell(double v) {
-    double f = floor((v + IG_HALF) / IG_BEL_CELL);
+    double f = floor((v + IG_HALF) * 2.0);  // / 0.5: a power of two, the product is the quotient bit for bit
     f = f < -1e6 ? -1e6 : (f > 1e6 ? 1e6 : f);
     return (int)f;
 }
