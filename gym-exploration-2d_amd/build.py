@@ -2,16 +2,25 @@
 
 The library is linked against the HIP runtime PyTorch-ROCm bundles (torch/lib/libamdhip64.so,
 SONAME libamdhip64.so.7) so that torch streams and device pointers are valid inside it.
+
+Translation units (compiled in parallel, objects cached under csrc/build/ by source + flag hash):
+  cagym_api.hip                      the C ABI, generation-1 kernels, reset / laserscan / raster / generator, GA3C, IG, Dec-MCTS
+  cagym_k3_tu.hip x 12               one per generation-3 specialisation (cagym_launch3.h: CAGYM_K3_SPECS x OBST)
 """
+import concurrent.futures
+import hashlib
 import os
 import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(CSRC, "libcagym_hip.so")
-SOURCES = ["cagym_api.hip"]
-HEADERS = ["cagym_device.h", "cagym_orca.h", "cagym_kernels.h", "cagym_kernels2.h", "cagym_kernels3.h", "cagym_ig.h", "cagym_ga3c.h", "cagym_gen.h", "cagym_dmcts.h", "../../include/cagym.h"]
+HEADERS = ["cagym_device.h", "cagym_orca.h", "cagym_kernels.h", "cagym_kernels3.h", "cagym_launch3.h", "cagym_ig.h", "cagym_ga3c.h",
+           "cagym_gen.h", "cagym_dmcts.h", "../../include/cagym.h"]
+K3_HEADERS = ["cagym_device.h", "cagym_orca.h", "cagym_kernels.h", "cagym_kernels3.h", "cagym_launch3.h", "../../include/cagym.h"]
+K3_SPECS = [(256, 10, 4), (256, 10, 5), (256, 4, 0), (256, 20, 2), (256, 0, 0), (512, 0, 0)]  # = CAGYM_K3_SPECS
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wno-unused-value",
@@ -20,33 +29,69 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-mllvm", "-disable-machine-licm"]
 
 
+def units():
+    """(object name, source, extra -D flags, headers it depends on)"""
+    u = [("cagym_api.o", "cagym_api.hip", [], HEADERS)]
+    for nt, mt, wp in K3_SPECS:
+        for ob in (0, 1):
+            u.append(("k3_%d_%d_%d_%d.o" % (nt, mt, wp, ob), "cagym_k3_tu.hip",
+                      ["-DK3_NT=%d" % nt, "-DK3_MT=%d" % mt, "-DK3_WP=%d" % wp, "-DK3_OBST=%d" % ob], K3_HEADERS))
+    return u
+
+
 def _torch_lib_dir():
     import torch
     return os.path.join(os.path.dirname(torch.__file__), "lib")
 
 
-def needs_build():
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
-    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+def _digest(src, defs, headers, extra):
+    h = hashlib.sha256()
+    for f in [src] + headers:
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    h.update(" ".join(FLAGS + defs + extra + [ARCH]).encode())
+    return h.hexdigest()
 
 
-def build(force=False, verbose=False):
-    if not force and not needs_build():
-        return LIB
+def _stale(extra):
+    out = []
+    for obj, src, defs, headers in units():
+        d = _digest(src, defs, headers, extra)
+        stamp = os.path.join(OBJ, obj + ".sha")
+        if not (os.path.exists(os.path.join(OBJ, obj)) and os.path.exists(stamp) and open(stamp).read() == d):
+            out.append((obj, src, defs, d))
+    return out
+
+
+def needs_build(extra=()):
+    return not os.path.exists(LIB) or bool(_stale(list(extra)))
+
+
+def _compile(job):
+    obj, src, defs, digest, extra, verbose = job
     hipcc = os.environ.get("HIPCC", "hipcc")
+    cmd = [hipcc, "--offload-arch=" + ARCH, "-c"] + FLAGS + defs + extra + ["-o", os.path.join(OBJ, obj), os.path.join(CSRC, src)]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    with open(os.path.join(OBJ, obj + ".sha"), "w") as fh:
+        fh.write(digest)
+    return obj
+
+
+def build(force=False, verbose=False, extra=(), jobs=None):
+    """extra: additional compiler flags for every unit (diagnostic builds)."""
+    extra = list(extra)
+    os.makedirs(OBJ, exist_ok=True)
+    todo = [(o, s, d, g) for (o, s, d, _h) in units() for g in [_digest(s, d, _h, extra)]] if force else _stale(extra)
+    if not todo and os.path.exists(LIB):
+        return LIB
+    jobs = jobs or min(len(todo), max(1, (os.cpu_count() or 2)))
+    if todo:
+        with concurrent.futures.ThreadPoolExecutor(max_workers=jobs) as ex:
+            list(ex.map(_compile, [(o, s, d, g, extra, verbose) for (o, s, d, g) in todo]))
     tl = _torch_lib_dir()
-    objs = []
-    for src in SOURCES:
-        obj = os.path.join(CSRC, src.replace(".hip", ".o"))
-        cmd = [hipcc, "--offload-arch=" + ARCH, "-c"] + FLAGS + ["-o", obj, os.path.join(CSRC, src)]
-        if verbose:
-            print(" ".join(cmd), file=sys.stderr)
-        subprocess.check_call(cmd)
-        objs.append(obj)
-    cmd = ["g++", "-shared", "-o", LIB] + objs + ["-L" + tl, "-lamdhip64", "-Wl,-rpath," + tl]
+    cmd = ["g++", "-shared", "-o", LIB] + [os.path.join(OBJ, u[0]) for u in units()] + ["-L" + tl, "-lamdhip64", "-Wl,-rpath," + tl]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

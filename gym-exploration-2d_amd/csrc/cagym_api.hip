@@ -9,7 +9,11 @@
 
 #include "../../include/cagym.h"
 #include "cagym_kernels.h"
-#include "cagym_kernels3.h"
+#include "cagym_kernels3.h"  // LDS layout helpers; the kernels themselves are instantiated in the cagym_k3_tu.hip units
+#include "cagym_launch3.h"
+#ifdef CAGYM_MONOLITHIC  // diagnostic builds: every generation-3 specialisation in this one translation unit
+#include "cagym_k3_all.inc"
+#endif
 #include "cagym_ig.h"
 #include "cagym_ga3c.h"
 #include "cagym_gen.h"
@@ -104,12 +108,8 @@ CagymOut to_out(const cagym_outputs* o) {
 //            4 worlds while every workgroup of the launch is co-resident (<= 5 per CU): ~28 live agents = one
 //            round of LP groups; measured 4096 worlds: 259 vs 247 M env-steps/s, 65536 worlds: 342 vs 392
 //   M = 20:  2 worlds, 380 unordered / 800 directed pair slots on 256 lanes (5 workgroups per CU instead of 2)
-#ifndef WPW20
 #define WPW20 2
-#endif
-#ifndef NT20
 #define NT20 256  /* lanes per workgroup of the M = 20 specialisation (512: 64 vs 78 M env-steps/s at 2048 x 20) */
-#endif
 // kernel specialisation of the handle: lanes per workgroup, compile-time M (0 = generic) and worlds per workgroup
 // (0 = 64 / M worlds, LDS stride 64)
 struct Spec2 {
@@ -135,6 +135,7 @@ inline size_t lds3_bytes(const Env* e, bool obst, bool lines) {
     return cagym_lds3_bytes(M, cagym_as(M, wpw_spec(e)), spec2(e).nt, (obst && lines) ? 2 * e->cfg.max_obstacles : 0, obst ? 4 : 2);
 }
 inline bool has_map(const Env* e) { return e->cfg.max_obstacles > 0; }
+inline size_t scan_bytes(const Env* e) { return (size_t)e->cfg.n_worlds * e->cfg.max_agents * 16 * sizeof(float); }
 inline size_t lds3_bytes(const Env* e) { return lds3_bytes(e, has_map(e), e->obst_rvo != 0); }
 // LP group width of the handle's specialisation (run_steps3)
 inline int lp_group_width(const Env* e) {
@@ -147,31 +148,31 @@ inline int n_waves(const Env* e) {
     return (e->cfg.n_worlds + wpw - 1) / wpw;
 }
 
-template <int NT, int MT, int WP>
-void set_lds_attr3(int lds3, int lds3_obst) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_step3<NT, MT, WP, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds3);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_step3<NT, MT, WP, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds3);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout3<NT, MT, WP, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds3);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout3<NT, MT, WP, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds3);
-    if (lds3_obst <= 160 * 1024) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_step3<NT, MT, WP, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds3_obst);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_step3<NT, MT, WP, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds3_obst);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout3<NT, MT, WP, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds3_obst);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout3<NT, MT, WP, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds3_obst);
-    }
-}
-
 // the one place that maps a handle to its kernel instantiation
-#define CAGYM_DISPATCH2(e, CALL)                                   \
-    do {                                                           \
-        const Spec2 _s = spec2(e);                                 \
-        if (_s.mt == 10 && _s.wpw == 4) { CALL(256, 10, 4); }      \
-        else if (_s.mt == 10) { CALL(256, 10, 5); }                \
-        else if (_s.mt == 4) { CALL(256, 4, 0); }                  \
-        else if (_s.mt == 20) { CALL(NT20, 20, WPW20); }           \
-        else if (_s.nt == 256) { CALL(256, 0, 0); }                \
-        else { CALL(512, 0, 0); }                                  \
-    } while (0)
+// (the launchers live in the per-specialisation translation units, cagym_k3_tu.hip)
+struct K3Entry {
+    int nt, mt, wp;
+    void (*launch[2])(const K3Launch&);  // [OBST]
+    void (*setattr[2])(int);
+};
+#define K3_ROW(NT, MT, WP)                                                                     \
+    {NT, MT, WP, {cagym_k3_launch_##NT##_##MT##_##WP##_0, cagym_k3_launch_##NT##_##MT##_##WP##_1}, \
+     {cagym_k3_setattr_##NT##_##MT##_##WP##_0, cagym_k3_setattr_##NT##_##MT##_##WP##_1}},
+const K3Entry k3_table[] = {CAGYM_K3_SPECS(K3_ROW)};
+#undef K3_ROW
+inline const K3Entry* k3_entry(const Env* e) {
+    const Spec2 sp = spec2(e);
+    for (const K3Entry& r : k3_table)
+        if (r.nt == sp.nt && r.mt == sp.mt && r.wp == sp.wpw) return &r;
+    return nullptr;
+}
+// one generation-3 launch of the handle's specialisation (free-space or OBST instantiation)
+inline void launch3(const Env* e, bool rollout, bool auto_reset, const float* ext, int n_steps, const CagymOut& o, hipStream_t st) {
+    K3Launch L;
+    L.D = e->D; L.ext = ext; L.out = o; L.n_steps = n_steps; L.any_rvo = e->any_rvo; L.rollout = rollout; L.auto_reset = auto_reset;
+    L.grid = (unsigned)n_wg2(e); L.lds = lds3_bytes(e); L.stream = st;
+    k3_entry(e)->launch[has_map(e) ? 1 : 0](L);
+}
 
 }  // namespace
 
@@ -248,6 +249,10 @@ int cagym_create(const cagym_config* cfg, void** env_out) {
     {
         const char* g = getenv("CAGYM_KERNEL");
         if (g && (!strcmp(g, "v1") || !strcmp(g, "1"))) e->generation = 1;
+        else if (g && g[0] && strcmp(g, "v3") && strcmp(g, "3")) {  // a retired or misspelt generation must not silently run the default
+            cagym_destroy(e);
+            return fail(nullptr, CAGYM_E_INVALID, std::string("CAGYM_KERNEL=") + g + ": unknown kernel generation (v1 or v3)");
+        }
         {
             hipDeviceProp_t prop;
             int cus = 256;
@@ -260,9 +265,9 @@ int cagym_create(const cagym_config* cfg, void** env_out) {
         int lds3 = (int)lds3_bytes(e, false, false), lds3_obst = (int)lds3_bytes(e, true, true);
         if (lds3_obst > 160 * 1024) lds3_obst = (int)lds3_bytes(e, true, false);  // too many rectangles for RVO agents: refused at set_scenarios
         if (e->generation == 3 && lds3 > 160 * 1024) e->generation = 1;
-#define SETATTR(NT, MT, WP) set_lds_attr3<NT, MT, WP>(lds3, lds3_obst)
-        CAGYM_DISPATCH2(e, SETATTR);
-#undef SETATTR
+        if (!k3_entry(e)) { cagym_destroy(e); return fail(nullptr, CAGYM_E_UNSUPPORTED, "no kernel specialisation for this shape"); }
+        k3_entry(e)->setattr[0](lds3);
+        if (lds3_obst <= 160 * 1024) k3_entry(e)->setattr[1](lds3_obst);
     }
     (void)hipGetLastError();
     *env_out = e;
@@ -292,9 +297,10 @@ int cagym_set_scenarios(void* env, const double* agents6, const double* heading0
         if (policy_id[k] < 0 || policy_id[k] > CAGYM_POL_IGMCTS) return fail(e, CAGYM_E_INVALID, "policy id out of range");
         if (dynamics_id[k] < 0 || dynamics_id[k] > CAGYM_DYN_FIRSTORDER) return fail(e, CAGYM_E_INVALID, "dynamics id out of range");
     }
-    e->any_rvo = 0;
+    // decided on locals, committed only after every validation and copy below succeeded: a refused call leaves the handle as it was
+    int new_any_rvo = 0, new_obst_rvo = 0, new_ko = 0;
     for (size_t k = 0; k < SM; k++)
-        if (policy_id[k] == CAGYM_POL_RVO) e->any_rvo = 1;
+        if (policy_id[k] == CAGYM_POL_RVO) new_any_rvo = 1;
     std::vector<int32_t> na(S), no(S, 0);
     for (size_t s = 0; s < S; s++) {
         na[s] = n_agents ? n_agents[s] : (int32_t)M;
@@ -309,9 +315,10 @@ int cagym_set_scenarios(void* env, const double* agents6, const double* heading0
     {
         bool any_obst = false;
         for (size_t sc = 0; sc < S; sc++) any_obst |= no[sc] > 0;
-        e->obst_rvo = (any_obst && e->any_rvo) ? 1 : 0;
-        e->D.ko = e->obst_rvo ? 2 * e->cfg.max_obstacles : 0;
-        if (e->obst_rvo) {
+        if (any_obst && !obstacles) return fail(e, CAGYM_E_INVALID, "n_obst > 0 needs the obstacles array");
+        new_obst_rvo = (any_obst && new_any_rvo) ? 1 : 0;
+        new_ko = new_obst_rvo ? 2 * e->cfg.max_obstacles : 0;
+        if (new_obst_rvo) {
             const int K = e->cfg.max_obstacles, gw = lp_group_width(e);
             const Spec2 sp = spec2(e);
             const int as = cagym_as((int)M, sp.wpw);
@@ -320,8 +327,7 @@ int cagym_set_scenarios(void* env, const double* agents6, const double* heading0
             // work item + 1 B per rank) borrow the LP3 scratch
             if (2 * K + (int)M - 1 > 4 * gw || 2 * K > 32 || (size_t)2 * K * as * 13 > (size_t)4 * sp.nt * 16 || lds3_bytes(e, true, true) > 160 * 1024)
                 return fail(e, CAGYM_E_UNSUPPORTED, "too many rectangles per world for RVO agents at this max_agents (2 * max_obstacles + max_agents - 1 half-planes per ego)");
-            if (obstacles)
-                for (size_t sc = 0; sc < S; sc++)
+            for (size_t sc = 0; sc < S; sc++)
                     for (int k = 0; k < no[sc]; k++) {
                         const double* r = obstacles + (sc * K + k) * 4;
                         if (!(r[2] > r[0]) || !(r[3] > r[1]))
@@ -387,6 +393,9 @@ int cagym_set_scenarios(void* env, const double* agents6, const double* heading0
     HIPCHK(e, hipStreamSynchronize(st));
     // a new pool restarts the episode numbering
     HIPCHK(e, hipMemsetAsync(D.episode, 0, e->cfg.n_worlds * sizeof(int32_t), st));
+    e->any_rvo = new_any_rvo;
+    e->obst_rvo = new_obst_rvo;
+    e->D.ko = new_ko;
     e->scenarios_set = true;
     return CAGYM_OK;
 }
@@ -477,18 +486,14 @@ int cagym_step(void* env, const float* ext_actions, const cagym_outputs* out, vo
     CagymOut o = to_out(out);
     if (!e->cfg.laserscan) o.laserscan = nullptr;
     if (e->generation == 3) {
-        const size_t lds3 = lds3_bytes(e);
-#define STEP3(NT, MT, WP)                                                                                                        \
-    do {                                                                                                                     \
-        if (has_map(e)) hipLaunchKernelGGL((k_step3<NT, MT, WP, false, true>), dim3(n_wg2(e)), dim3(NT), lds3, st, e->D, ext_actions, o, e->any_rvo); \
-        else hipLaunchKernelGGL((k_step3<NT, MT, WP, false, false>), dim3(n_wg2(e)), dim3(NT), lds3, st, e->D, ext_actions, o, e->any_rvo);       \
-    } while (0)
-        CAGYM_DISPATCH2(e, STEP3);
-#undef STEP3
+        launch3(e, false, false, ext_actions, 1, o, st);
     } else
     hipLaunchKernelGGL(k_step, dim3(n_waves(e)), dim3(64), cagym_lds_bytes(e->cfg.max_agents), st, e->D, ext_actions, o);
     HIPCHK(e, hipGetLastError());
     if (e->generation != 3 && e->cfg.laserscan && o.laserscan) return cagym_laserscan(env, o.laserscan, stream);  // generation 3 scans in-kernel
+    // ... in its OBST instantiation; a handle without rectangles runs the free-space kernels: every beam of an empty map reads 0.0
+    // (LaserScanSensor.py:27-58 on an all-free Map)
+    if (e->generation == 3 && !has_map(e) && o.laserscan) HIPCHK(e, hipMemsetAsync(o.laserscan, 0, scan_bytes(e), st));
     return CAGYM_OK;
 }
 
@@ -501,17 +506,11 @@ int cagym_step_autoreset(void* env, const float* ext_actions, const cagym_output
     CagymOut o = to_out(out);
     if (!e->cfg.laserscan) o.laserscan = nullptr;
     if (e->generation == 3) {
-        const size_t lds3 = lds3_bytes(e);
-#define STEP3(NT, MT, WP)                                                                                                        \
-    do {                                                                                                                     \
-        if (has_map(e)) hipLaunchKernelGGL((k_step3<NT, MT, WP, true, true>), dim3(n_wg2(e)), dim3(NT), lds3, st, e->D, ext_actions, o, e->any_rvo); \
-        else hipLaunchKernelGGL((k_step3<NT, MT, WP, true, false>), dim3(n_wg2(e)), dim3(NT), lds3, st, e->D, ext_actions, o, e->any_rvo);       \
-    } while (0)
-        CAGYM_DISPATCH2(e, STEP3);
-#undef STEP3
+        launch3(e, false, true, ext_actions, 1, o, st);
     } else
         return fail(e, CAGYM_E_UNSUPPORTED, "cagym_step_autoreset needs the generation-3 kernels");
     HIPCHK(e, hipGetLastError());
+    if (!has_map(e) && o.laserscan) HIPCHK(e, hipMemsetAsync(o.laserscan, 0, scan_bytes(e), st));  // empty map: 0.0 everywhere
     return CAGYM_OK;  // the scan of the (possibly restarted) worlds is part of the launch
 }
 
@@ -528,22 +527,14 @@ int cagym_rollout(void* env, int n_steps, int auto_reset, const cagym_outputs* o
     if (!e->cfg.laserscan) o.laserscan = nullptr;
     size_t lds = cagym_lds_bytes(e->cfg.max_agents);
     if (e->generation == 3) {
-        const size_t lds3 = lds3_bytes(e);
-        const dim3 g(n_wg2(e));
-#define ROLL3(NT, MT, WP)                                                                                              \
-    do {                                                                                                           \
-        if (auto_reset && has_map(e)) hipLaunchKernelGGL((k_rollout3<NT, MT, WP, true, true>), g, dim3(NT), lds3, st, e->D, n_steps, o, e->any_rvo); \
-        else if (auto_reset) hipLaunchKernelGGL((k_rollout3<NT, MT, WP, true, false>), g, dim3(NT), lds3, st, e->D, n_steps, o, e->any_rvo); \
-        else if (has_map(e)) hipLaunchKernelGGL((k_rollout3<NT, MT, WP, false, true>), g, dim3(NT), lds3, st, e->D, n_steps, o, e->any_rvo); \
-        else hipLaunchKernelGGL((k_rollout3<NT, MT, WP, false, false>), g, dim3(NT), lds3, st, e->D, n_steps, o, e->any_rvo);         \
-    } while (0)
-        CAGYM_DISPATCH2(e, ROLL3);
-#undef ROLL3
+        launch3(e, true, auto_reset != 0, nullptr, n_steps, o, st);
     } else if (auto_reset)
         hipLaunchKernelGGL(k_rollout<true>, dim3(n_waves(e)), dim3(64), lds, st, e->D, n_steps, o);
     else
         hipLaunchKernelGGL(k_rollout<false>, dim3(n_waves(e)), dim3(64), lds, st, e->D, n_steps, o);
     HIPCHK(e, hipGetLastError());
+    if (e->generation == 3 && !has_map(e) && o.laserscan)  // empty map: 0.0 everywhere, all n_steps slices
+        HIPCHK(e, hipMemsetAsync(o.laserscan, 0, (size_t)n_steps * scan_bytes(e), st));
     return CAGYM_OK;
 }
 
@@ -552,8 +543,8 @@ int cagym_kernel_name(void* env, int rollout, int auto_reset, char* buf, int buf
     if (!e || !buf || buf_len < 1) return fail(e, CAGYM_E_INVALID, "bad arguments");
     if (e->generation == 3) {
         const Spec2 sp = spec2(e);
-        snprintf(buf, (size_t)buf_len, "%s%d<%d, %d, %d, %s>", rollout ? "k_rollout" : "k_step", e->generation, sp.nt, sp.mt,
-                 sp.wpw, auto_reset ? "true" : "false");
+        snprintf(buf, (size_t)buf_len, "%s%d<%d, %d, %d, %s, %s>", rollout ? "k_rollout" : "k_step", e->generation, sp.nt, sp.mt,
+                 sp.wpw, auto_reset ? "true" : "false", has_map(e) ? "true" : "false");
     } else if (rollout) {
         snprintf(buf, (size_t)buf_len, "k_rollout<%s>", auto_reset ? "true" : "false");
     } else {

@@ -323,6 +323,7 @@ __device__ __forceinline__ LaneCtx make_ctx(const CagymDev& D) {
 }
 
 // env.step(): one launch per step (external actions allowed).
+#ifndef CAGYM_K3_UNIT  // the generation-3 units include this header for its device functions only
 __global__ void __launch_bounds__(64) k_step(CagymDev D, const float* ext, CagymOut out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     WaveLds W = carve_lds(smem, D.M);
@@ -341,8 +342,10 @@ __global__ void __launch_bounds__(64) k_step(CagymDev D, const float* ext, Cagym
         if (C.slot == 0) { D.ep_return[C.world] = ep_ret; D.ep_len[C.world] = ep_len; }
     }
 }
+#endif
 
 // n_steps env.step() calls in one launch, state in registers, outputs to slice t (cagym_rollout).
+#ifndef CAGYM_K3_UNIT  // the generation-3 units include this header for its device functions only
 template <bool AUTO_RESET>
 __global__ void __launch_bounds__(64) k_rollout(CagymDev D, int n_steps, CagymOut out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -377,8 +380,10 @@ __global__ void __launch_bounds__(64) k_rollout(CagymDev D, int n_steps, CagymOu
         }
     }
 }
+#endif
 
 // reset() (env.py:234-266) for masked worlds.
+#ifndef CAGYM_K3_UNIT  // the generation-3 units include this header for its device functions only
 __global__ void __launch_bounds__(64) k_reset(CagymDev D, const uint8_t* mask, int advance, CagymOut out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     WaveLds W = carve_lds(smem, D.M);
@@ -425,6 +430,7 @@ __global__ void __launch_bounds__(64) k_reset(CagymDev D, const uint8_t* mask, i
     }
     sense_and_store(D, W, C, A, out, wr, false);
 }
+#endif
 
 // LaserScanSensor.sense (sensors/LaserScanSensor.py:9-22,27-58), beam b of an agent at (px, py, heading h) with
 // `radius`: 16 samples at 2 pi / 16 m into the bit-packed raster `map` (null = empty map), the agent's own disk masked,
@@ -468,6 +474,7 @@ __device__ __forceinline__ float laserscan_beam(const uint32_t* map, double px, 
 }
 
 // one lane per (agent, beam) of the state in HBM (cagym_laserscan, cagym_reset)
+#ifndef CAGYM_K3_UNIT  // the generation-3 units include this header for its device functions only
 __global__ void __launch_bounds__(256) k_laserscan(CagymDev D, float* out) {
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t total = (size_t)D.N * D.M * 16;
@@ -480,6 +487,7 @@ __global__ void __launch_bounds__(256) k_laserscan(CagymDev D, float* out) {
     const uint32_t* map = (D.map_bits && D.sc_nobst[sidx] > 0) ? D.map_bits + (size_t)sidx * CAGYM_MAPD * CAGYM_MAPW : nullptr;
     out[gid] = laserscan_beam(map, D.px[a], D.py[a], D.heading[a], D.radius[a], b);
 }
+#endif
 
 // OccupancyGridSensor.sense (sensors/OccupancyGridSensor.py:70-98, 131-143; Map.getSubmapByIndices Map.py:81-105):
 // the occupancy raster rotated about the agent's cell by -heading (cv2.getRotationMatrix2D + cv2.warpAffine,
@@ -496,6 +504,7 @@ __device__ __forceinline__ int og_submap_start(int c) {
     if (si + 60 > CAGYM_MAPD - 1) si = CAGYM_MAPD - 1 - 60;
     return (int)si;
 }
+#ifndef CAGYM_K3_UNIT  // the generation-3 units include this header for its device functions only
 __global__ void __launch_bounds__(256) k_occupancy_grid(CagymDev D, uint8_t* out) {
     const size_t a = blockIdx.x;
     const int world = (int)(a / D.M), slot = (int)(a - (size_t)world * D.M);
@@ -539,8 +548,10 @@ __global__ void __launch_bounds__(256) k_occupancy_grid(CagymDev D, uint8_t* out
         o[q] = (uint8_t)v;
     }
 }
+#endif
 
 // Map.get_occupancy_grid (Map.py:107-123): one workgroup per scenario, bit-packed output.
+#ifndef CAGYM_K3_UNIT  // the generation-3 units include this header for its device functions only
 __global__ void __launch_bounds__(256) k_rasterize(const double* obst, const int32_t* nobst, int Kobs, uint32_t* map_bits) {
     const int s = blockIdx.x;
     uint32_t* map = map_bits + (size_t)s * CAGYM_MAPD * CAGYM_MAPW;
@@ -567,6 +578,7 @@ __global__ void __launch_bounds__(256) k_rasterize(const double* obst, const int
         __syncthreads();
     }
 }
+#endif
 
 // GA3CCADRLPolicy.agents_to_ga3c_cadrl_state (policies/GA3CCADRLPolicy.py:45-106): LPA lanes per agent (lane j <-> other agent
 // j: its distance, sort key and feature row; the rank is a count over the keys the agent's lanes left in LDS),
@@ -574,6 +586,7 @@ __global__ void __launch_bounds__(256) k_rasterize(const double* obst, const int
 // flat agent (world * M + slot); others ordered by (-round(d,2), p_orth), stable, last `max_observed` kept.  Zero rows for
 // inactive slots.  agent_idx == null: every agent slot of the handle; else the B (or *B_dev) listed agents only - the
 // reference builds the vector for the GA3C agent alone (find_next_action is per agent).
+#ifndef CAGYM_K3_UNIT  // the generation-3 units include this header for its device functions only
 template <int LPA>
 __global__ void __launch_bounds__(256) k_ga3c_state(CagymDev D, int max_observed, const int32_t* __restrict__ agent_idx, int B,
                                                     const int32_t* __restrict__ B_dev, float* out) {
@@ -644,9 +657,11 @@ __global__ void __launch_bounds__(256) k_ga3c_state(CagymDev D, int max_observed
         o[5] = (float)ri;
     }
 }
+#endif
 
 // indices (world * M + slot) of the active agents whose policy id is CAGYM_POL_GA3C, compacted on the device (order within
 // the list is not fixed: every consumer treats the listed agents independently).  *count must be zero on entry.
+#ifndef CAGYM_K3_UNIT  // the generation-3 units include this header for its device functions only
 __global__ void __launch_bounds__(1024) k_ga3c_select(CagymDev D, int32_t* idx, int32_t* count) {
     // one returning atomic per 1024-thread block (all of them hit one L2 address: per-wave atomics took 16 us for 81 920 slots)
     __shared__ int wave_cnt[16], wave_base[16];
@@ -670,3 +685,4 @@ __global__ void __launch_bounds__(1024) k_ga3c_select(CagymDev D, int32_t* idx, 
     __syncthreads();
     if (take) idx[wave_base[wave] + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)a;
 }
+#endif

@@ -623,35 +623,30 @@ static int orca_obstacle_lines(const double* rects, int n_obst, float px, float 
     return nl;
 }
 
-/* RVOPolicy.find_next_action (policies/RVOPolicy.py:53-117), ego LP only.
- * Simulator parameters RVOPolicy.py:25-28: timeStep 0.1, neighborDist inf, maxNeighbors =
- * Config.MAX_NUM_AGENTS_IN_ENVIRONMENT (RVOPolicy.py:15), timeHorizon = timeHorizonObst = 5.  Neighbours are visited in
- * index order (the real library's k-d tree order is unpinned), nearest first, at most max_neighbors.  collab:
- * line.point = v + collab*u (assumed semantics of the mit-acl fork's setAgentCollabCoeff; stock RVO2 uses 0.5).
- * rects [n_obst][4] = xl, yl, xu, yu (may be NULL): obstacle lines come first and are hard constraints in
- * linearProgram3.  new_vel_out (optional): the fp32 velocity the linear programs chose, lines_out / n_lines_out
- * (optional): the half-planes in solve order and {numObstLines, total}. */
-void cao_orca_action_ex(int M, int ego, const double* pos, const double* vel, const double* goal,
-                        const double* pref_speed, const double* radius, double heading, double collab,
-                        double dt, int max_neighbors, const double* rects, int n_obst, double* action_out,
-                        float* new_vel_out, float* lines_out, int* n_lines_out) {
-    float p[64][2], v[64][2], r[64];
-    for (int a = 0; a < M; a++) {
-        p[a][0] = (float)pos[2 * a]; p[a][1] = (float)pos[2 * a + 1];
-        v[a][0] = (float)vel[2 * a]; v[a][1] = (float)vel[2 * a + 1];
-        r[a] = (float)((1 + 15e-2) * radius[a]);
-    }
-    double gx = goal[2 * ego] - pos[2 * ego], gy = goal[2 * ego + 1] - pos[2 * ego + 1];
-    double sc = pref_speed[ego] / norm2(gx, gy);
-    float pvx = (float)(sc * gx), pvy = (float)(sc * gy);
-    float max_speed = (float)pref_speed[ego];
-    float time_step = (float)dt, time_horizon = 5.0f;
+/* ---- the LIBRARY half: what rvo2.PyRVOSimulator.doStep() computes for one agent of the simulator ----------------
+ * (RVO2 v2.0 Agent::computeNeighbors + computeNewVelocity + update; library absent: PARITY UNPINNED).
+ * All inputs are what the Python side handed over through the simulator's setters, already narrowed to float by the
+ * Cython binding.  Neighbours are visited in index order (the real library's k-d tree order is unpinned), nearest
+ * first, at most max_neighbors, closer than neighbor_dist.  collab: line.point = v + collab*u (assumed semantics of
+ * the mit-acl fork's setAgentCollabCoeff; stock RVO2 uses 0.5).  rects [n_obst][4] = xl, yl, xu, yu (may be NULL):
+ * obstacle lines come first and are hard constraints in linearProgram3.
+ * tests/golden/rvo2_standin.py calls THIS function from inside the unmodified reference (RVOPolicy.py:88), so the
+ * reference-run fixtures pin everything of RVOPolicy.py:53-117 around it. */
+void cao_rvo2_step_agent(int n, int ego, const float* pos, const float* vel, const float* radius,
+                         const float* pref_vel2, float max_speed, float collab, float neighbor_dist, int max_neighbors,
+                         float time_horizon, float time_horizon_obst, float time_step, const double* rects, int n_obst,
+                         float* new_pos2, float* new_vel2, float* lines_out, int* n_lines_out) {
+    const float (*p)[2] = (const float (*)[2])pos;
+    const float (*v)[2] = (const float (*)[2])vel;
+    const float* r = radius;
+    const float pvx = pref_vel2[0], pvy = pref_vel2[1];
     /* neighbour list: insertion by distSq, strict <, at most maxNeighbors (Agent::insertAgentNeighbor) */
     int nb[64]; float nd[64]; int nn = 0;
+    if (n > 64) n = 64;
     if (max_neighbors < 0) max_neighbors = 0;
     if (max_neighbors > 63) max_neighbors = 63;
-    float range_sq = INFINITY;
-    for (int a = 0; a < M; a++) {
+    float range_sq = neighbor_dist * neighbor_dist; /* rangeSq = sqr(neighborDist_) */
+    for (int a = 0; a < n; a++) {
         if (a == ego) continue;
         float dx = p[ego][0] - p[a][0], dy = p[ego][1] - p[a][1];
         float dsq = dx * dx + dy * dy;
@@ -665,11 +660,11 @@ void cao_orca_action_ex(int M, int ego, const double* pos, const double* vel, co
     }
     orca_line Lall[CAO_MAXLINES];
     const int num_obst = (rects && n_obst > 0)
-        ? orca_obstacle_lines(rects, n_obst, p[ego][0], p[ego][1], v[ego][0], v[ego][1], r[ego], max_speed, time_horizon, Lall)
+        ? orca_obstacle_lines(rects, n_obst, p[ego][0], p[ego][1], v[ego][0], v[ego][1], r[ego], max_speed, time_horizon_obst, Lall)
         : 0;
     orca_line* L = Lall + num_obst;
     float inv_th = 1.0f / time_horizon;
-    float c = (float)collab;
+    float c = collab;
     for (int k = 0; k < nn; k++) {
         int o = nb[k];
         float rpx = p[o][0] - p[ego][0], rpy = p[o][1] - p[ego][1];
@@ -720,7 +715,7 @@ void cao_orca_action_ex(int M, int ego, const double* pos, const double* vel, co
     const int nl = num_obst + nn;
     int fail = lp2(Lall, nl, max_speed, pvx, pvy, 0, &nvx, &nvy);
     if (fail < nl) lp3(Lall, nl, num_obst, fail, max_speed, &nvx, &nvy);
-    if (new_vel_out) { new_vel_out[0] = nvx; new_vel_out[1] = nvy; }
+    if (new_vel2) { new_vel2[0] = nvx; new_vel2[1] = nvy; }
     if (n_lines_out) { n_lines_out[0] = num_obst; n_lines_out[1] = nl; }
     if (lines_out)
         for (int k = 0; k < nl; k++) {
@@ -728,9 +723,45 @@ void cao_orca_action_ex(int M, int ego, const double* pos, const double* vel, co
             lines_out[4 * k + 2] = Lall[k].dx; lines_out[4 * k + 3] = Lall[k].dy;
         }
     /* Agent::update: position_ += velocity_ * timeStep_ (fp32) */
-    float npx = p[ego][0] + nvx * time_step, npy = p[ego][1] + nvy * time_step;
+    new_pos2[0] = p[ego][0] + nvx * time_step;
+    new_pos2[1] = p[ego][1] + nvy * time_step;
+}
+
+/* ---- the PYTHON half before doStep(): what RVOPolicy.find_next_action hands to its private simulator ---------------
+ * (policies/RVOPolicy.py:63-85; simulator parameters :25-28: timeStep = Config.DT, neighborDist = SENSING_HORIZON = inf,
+ * maxNeighbors = Config.MAX_NUM_AGENTS_IN_ENVIRONMENT (:15), timeHorizon = timeHorizonObst = RVO_TIME_HORIZON = 5).
+ * Every agent of the env (done or not, any policy) is an agent of the simulator: position, velocity, 1.15 * radius
+ * (:76), maxSpeed = pref_speed (:75); the ego's preferred velocity pref_speed / ||g - p|| * (g - p) in fp64 (:71-72);
+ * the ego's cooperation_coef (:85).  Narrowed to float where the Cython binding narrows.  PINNED by the setter
+ * arguments recorded in tests/golden/rvo_episodes.npz. */
+void cao_rvo_sim_inputs(int M, int ego, const double* pos, const double* vel, const double* goal,
+                        const double* pref_speed, const double* radius, double collab,
+                        float* p32, float* v32, float* r32, float* pref_vel2, float* max_speed, float* collab32) {
+    for (int a = 0; a < M; a++) {
+        p32[2 * a] = (float)pos[2 * a]; p32[2 * a + 1] = (float)pos[2 * a + 1];
+        v32[2 * a] = (float)vel[2 * a]; v32[2 * a + 1] = (float)vel[2 * a + 1];
+        r32[a] = (float)((1 + 15e-2) * radius[a]);
+    }
+    double gx = goal[2 * ego] - pos[2 * ego], gy = goal[2 * ego + 1] - pos[2 * ego + 1];
+    double sc = pref_speed[ego] / norm2(gx, gy);
+    pref_vel2[0] = (float)(sc * gx); pref_vel2[1] = (float)(sc * gy);
+    *max_speed = (float)pref_speed[ego];
+    *collab32 = (float)collab;
+}
+
+/* RVOPolicy.find_next_action (policies/RVOPolicy.py:53-117), ego LP only = the two Python halves around
+ * the library call.  new_vel_out (optional): the fp32 velocity the linear programs chose, lines_out / n_lines_out
+ * (optional): the half-planes in solve order and {numObstLines, total}. */
+void cao_orca_action_ex(int M, int ego, const double* pos, const double* vel, const double* goal,
+                        const double* pref_speed, const double* radius, double heading, double collab,
+                        double dt, int max_neighbors, const double* rects, int n_obst, double* action_out,
+                        float* new_vel_out, float* lines_out, int* n_lines_out) {
+    float p[64][2], v[64][2], r[64], pv[2], max_speed, c, np2[2];
+    cao_rvo_sim_inputs(M, ego, pos, vel, goal, pref_speed, radius, collab, &p[0][0], &v[0][0], r, pv, &max_speed, &c);
+    cao_rvo2_step_agent(M, ego, &p[0][0], &v[0][0], r, pv, max_speed, c, INFINITY, max_neighbors, 5.0f, 5.0f, (float)dt,
+                        rects, n_obst, np2, new_vel_out, lines_out, n_lines_out);
     /* back in Python, fp64 (RVOPolicy.py:91-106) */
-    double dpx = (double)npx - pos[2 * ego], dpy = (double)npy - pos[2 * ego + 1];
+    double dpx = (double)np2[0] - pos[2 * ego], dpy = (double)np2[1] - pos[2 * ego + 1];
     double ang1 = atan2(dpy, dpx);
     /* (ang1 - 0) % (2*pi), Python float modulo; |ang1| <= pi so fmod(ang1, 2*pi) == ang1 exactly */
     double nh = ang1;

@@ -90,6 +90,17 @@ void cao_orca_action_ex(int M, int ego, const double* pos, const double* vel, co
                         double dt, int max_neighbors, const double* rects, int n_obst, double* action_out,
                         float* new_vel_out, float* lines_out, int* n_lines_out);
 
+/* The two halves of the above, separately (tests/golden/rvo2_standin.py runs the unmodified reference RVOPolicy on top
+ * of cao_rvo2_step_agent; tests compare cao_rvo_sim_inputs with the setter arguments the reference recorded):
+ * what RVOPolicy.py:63-85 hands to the simulator (float-narrowed), and what doStep() makes of it for one agent. */
+void cao_rvo_sim_inputs(int M, int ego, const double* pos, const double* vel, const double* goal,
+                        const double* pref_speed, const double* radius, double collab,
+                        float* p32, float* v32, float* r32, float* pref_vel2, float* max_speed, float* collab32);
+void cao_rvo2_step_agent(int n, int ego, const float* pos, const float* vel, const float* radius,
+                         const float* pref_vel2, float max_speed, float collab, float neighbor_dist, int max_neighbors,
+                         float time_horizon, float time_horizon_obst, float time_step, const double* rects, int n_obst,
+                         float* new_pos2, float* new_vel2, float* lines_out, int* n_lines_out);
+
 /* GA3C-CADRL state vectors out[N,M,76] (policies/GA3CCADRLPolicy.py:45-106) */
 void cao_ga3c_states(cao_env* e, int max_observed, double* out);
 

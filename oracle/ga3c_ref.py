@@ -46,3 +46,14 @@ def forward(W, x75):
     p = np.exp(lg - lg.max(axis=1, keepdims=True))
     p /= p.sum(axis=1, keepdims=True)
     return (p + 1e-4) / (1.0 + 1e-4 * 11)
+
+
+def find_next_action(W, state76, pref_speed):
+    """GA3CCADRLPolicy.find_next_action (policies/GA3CCADRLPolicy.py:34-43) after the state vector: obs[1:] -> predict_p
+    -> argmax -> network.Actions row -> [pref_speed * a0, a1], then the env's float32 action table (env.py:289).
+    state76 [B, 76], pref_speed [B].  Returns (actions [B, 2] float32-valued, probabilities [B, 11])."""
+    st = np.asarray(state76, dtype=np.float64).reshape(-1, 76)
+    p = forward(W, st[:, 1:])
+    raw = action_table()[np.argmax(p, axis=1)]
+    act = np.stack([np.asarray(pref_speed, dtype=np.float64).reshape(-1) * raw[:, 0], raw[:, 1]], axis=1)
+    return act.astype(np.float32).astype(np.float64), p

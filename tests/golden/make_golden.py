@@ -123,9 +123,26 @@ def snapshot(env, rec, rewards, game_over, laser):
     rec['game_over'].append(bool(game_over))
 
 
+def _policy_classes():
+    """RVO / GA3C policy classes of the reference on top of the delegating stand-ins (rvo2_standin.py, ga3c_standin.py):
+    imported lazily, the other fixture groups never touch them."""
+    if scen.POLICY_RVO not in POLICIES:
+        import rvo2_standin
+        import ga3c_standin
+        rvo2_standin.install(sys.modules["rvo2"])
+        with rh.quiet():
+            from gym_collision_avoidance.envs.policies.RVOPolicy import RVOPolicy
+            from gym_collision_avoidance.envs.policies.GA3C_CADRL import network
+            ga3c_standin.install(network)
+            from gym_collision_avoidance.envs.policies.GA3CCADRLPolicy import GA3CCADRLPolicy
+        POLICIES[scen.POLICY_RVO] = RVOPolicy
+        POLICIES[scen.POLICY_GA3C] = GA3CCADRLPolicy
+    return POLICIES
+
+
 def run_case(agents6, policy_id, dynamics_id, heading0=None, obstacles=(), laser=False,
              ext_actions=None, max_steps=220, extra=3, evaluate=True, homogeneous=False,
-             single=False, m_max=10):
+             single=False, m_max=10, coop=None):
     agents6 = np.asarray(agents6, dtype=np.float64)
     M = agents6.shape[0]
     policy_id = np.broadcast_to(np.asarray(policy_id), (M,)).astype(np.int32)
@@ -138,12 +155,21 @@ def run_case(agents6, policy_id, dynamics_id, heading0=None, obstacles=(), laser
     Config.HOMOGENEOUS_TESTING = homogeneous
     Config.TRAIN_SINGLE_AGENT = False  # rewards for all M agents; scalar mode is rewards[0] (env.py:565-566)
     sensors = [OtherAgentsStatesSensor] + ([LaserScanSensor] if laser else [])
+    has_rvo = bool((policy_id == scen.POLICY_RVO).any())
+    has_ga3c = bool((policy_id == scen.POLICY_GA3C).any())
+    if has_rvo or has_ga3c:
+        _policy_classes()
+        import rvo2_standin
+        import ga3c_standin
+    coop = np.ones(M) if coop is None else np.broadcast_to(np.asarray(coop, dtype=np.float64), (M,)).copy()
     with rh.quiet():
         agents = [Agent(agents6[i, 0], agents6[i, 1], agents6[i, 2], agents6[i, 3], agents6[i, 5], agents6[i, 4],
                         np.float64(heading0[i]), POLICIES[int(policy_id[i])], DYNAMICS[int(dynamics_id[i])],
-                        sensors, i) for i in range(M)]
+                        sensors, i, cooperation_coef=float(coop[i])) for i in range(M)]
         for a in agents:
             a.policy.targetMap = None
+            if int(policy_id[a.id]) == scen.POLICY_GA3C:
+                a.policy.initialize_network()  # as test_cases.py:541 / env.py:454 do
         env = OracleEnv()
         env.oracle_obstacles = [rect(*o) for o in obstacles]
         env.set_agents(agents)
@@ -159,6 +185,10 @@ def run_case(agents6, policy_id, dynamics_id, heading0=None, obstacles=(), laser
     T = max_steps if ext_actions is None else min(max_steps, len(ext_actions))
     after = None
     used = []
+    # what the reference handed to its RVO simulators / its network at every step (stand-in logs)
+    sim = {k: [] for k in ('called', 'pos', 'vel', 'radius', 'pref', 'max_speed', 'collab', 'n_rects', 'n_added', 'new_pos')}
+    net = {k: [] for k in ('called', 'x', 'p', 'action')}
+    sim_params = None
     for s in range(T):
         if ext_actions is None:
             acts = {}
@@ -178,8 +208,46 @@ def run_case(agents6, policy_id, dynamics_id, heading0=None, obstacles=(), laser
                 finally:
                     Config.TRAIN_SINGLE_AGENT = False
             env._check_which_agents_done = patched
+            if has_rvo:
+                del rvo2_standin.LOG[:]
+            if has_ga3c:
+                del ga3c_standin.LOG[:]
+            was_done = [bool(a.is_done) for a in env.agents]
             _, rewards, game_over, info = env.step(acts)
             env._check_which_agents_done = orig
+        if has_rvo:
+            # one doStep() per live RVO agent, in agent order (env.py:296-320)
+            egos = [i for i in range(M) if policy_id[i] == scen.POLICY_RVO and not was_done[i]]
+            assert len(rvo2_standin.LOG) == len(egos), (len(rvo2_standin.LOG), egos)
+            rec_s = {'called': np.zeros(M, dtype=bool), 'pos': np.zeros((M, M, 2), np.float32),
+                     'vel': np.zeros((M, M, 2), np.float32), 'radius': np.zeros((M, M), np.float32),
+                     'pref': np.zeros((M, 2), np.float32), 'max_speed': np.zeros(M, np.float32),
+                     'collab': np.zeros(M, np.float32), 'n_rects': np.zeros(M, np.int32),
+                     'n_added': np.zeros(M, np.int32), 'new_pos': np.zeros((M, 2), np.float32)}
+            for i, lg in zip(egos, rvo2_standin.LOG):
+                assert lg['collab_set'] == [i]  # only the ego's coefficient is ever set (RVOPolicy.py:85)
+                rec_s['called'][i] = True
+                rec_s['pos'][i], rec_s['vel'][i], rec_s['radius'][i] = lg['pos'], lg['vel'], lg['radius']
+                rec_s['pref'][i], rec_s['max_speed'][i], rec_s['collab'][i] = lg['pref'][i], lg['max_speed'][i], lg['collab'][i]
+                rec_s['n_rects'][i], rec_s['n_added'][i] = len(lg['rects']), lg['n_added']
+                rec_s['new_pos'][i] = env.agents[i].policy.new_rvo_pos
+                if len(lg['rects']):
+                    assert np.array_equal(lg['rects'], np.asarray(obstacles, dtype=np.float64).reshape(-1, 4))
+                sim_params = lg['params'] if sim_params is None else sim_params
+                assert np.array_equal(sim_params, lg['params'])
+            for k in sim:
+                sim[k].append(rec_s[k])
+        if has_ga3c:
+            egos = [i for i in range(M) if policy_id[i] == scen.POLICY_GA3C and not was_done[i]]
+            assert len(ga3c_standin.LOG) == len(egos)
+            rec_n = {'called': np.zeros(M, dtype=bool), 'x': np.zeros((M, 75)), 'p': np.zeros((M, 11)),
+                     'action': np.zeros((M, 2))}
+            for i, (x, p_) in zip(egos, ga3c_standin.LOG):
+                rec_n['called'][i] = True
+                rec_n['x'][i], rec_n['p'][i] = x[0], p_[0]
+                rec_n['action'][i] = env.agents[i].past_actions[0]  # the fp32-rounded action the env applied
+            for k in net:
+                net[k].append(rec_n[k])
         snapshot(env, rec, rewards, game_over, laser)
         used.append(s)
         if all(a.is_done for a in env.agents):
@@ -194,6 +262,16 @@ def run_case(agents6, policy_id, dynamics_id, heading0=None, obstacles=(), laser
     out['obstacles'] = np.asarray(obstacles, dtype=np.float64).reshape(-1, 4)
     if ext_actions is not None:
         out['ext_actions'] = np.asarray(ext_actions[:len(used)], dtype=np.float64)
+    out['coop'] = coop
+    if has_rvo:
+        for k, v in sim.items():
+            out['sim_' + k] = np.array(v)
+        out['sim_params'] = sim_params  # timeStep, neighborDist, maxNeighbors, timeHorizon, timeHorizonObst
+    if has_ga3c:
+        for k, v in net.items():
+            out['net_' + k] = np.array(v)
+        assert ext_actions is None
+        out['ext_actions'] = out['net_action'].copy()  # a backend without the network replays these (POLICY_GA3C = external)
     out['cfg'] = np.array([int(evaluate), int(homogeneous), int(single), int(m_max), int(laser)], dtype=np.int32)
     return out
 
@@ -516,6 +594,92 @@ def dmcts_reference(n_seeds=6, n_steps=6):
 
 
 
+def rvo_episodes():
+    """UNMODIFIED reference episodes with RVOPolicy agents on top of the delegating rvo2 stand-in (rvo2_standin.py): pins
+    RVOPolicy.py:53-117 (simulator inputs incl. the 1.15 radius, pref velocity, collab coefficient; the post-processing to
+    (speed, delta heading) with the pi/6 stop-and-turn clamp), one private simulator per RVO agent (Q22), obstacles
+    processed once (Q21), done / static / non-cooperative agents as neighbours.  The LP arithmetic itself is the oracle's."""
+    U, NC, ST, RVO = scen.DYN_UNICYCLE, scen.POLICY_NONCOOP, scen.POLICY_STATIC, scen.POLICY_RVO
+    cases = {}
+    with rh.quiet():
+        P4, P10 = tc.preset_testCases(4), tc.preset_testCases(10)
+    pr = np.random.default_rng(777)
+
+    def jitter(c, amp=0.07):
+        c = np.array(c, dtype=np.float64)
+        c[:, 0:4] += pr.uniform(-amp, amp, c[:, 0:4].shape)
+        return c
+    cases["m4_cross"] = run_case(jitter(P4[2]), RVO, U, homogeneous=True, coop=0.5)
+    c = jitter(P4[0])
+    cases["m4_swap_coop"] = run_case(c, RVO, U, homogeneous=True, coop=[1.0, 0.5, 0.0, 0.3][:len(c)])
+    cases["m10_circle"] = run_case(jitter(P10[0]), RVO, U, homogeneous=True, coop=0.5, max_steps=260)
+    for wi in range(3):
+        w = scen.random_world(np.random.default_rng(9100 + wi), 10)
+        cases["m10_w%d" % wi] = run_case(w, RVO, U, homogeneous=True, coop=0.5, max_steps=260)
+    w = scen.random_world(np.random.default_rng(9200), 4)
+    cases["m4_w0"] = run_case(w, RVO, U, homogeneous=True, coop=0.5)
+    # mixes: static and non-cooperative neighbours, agents that finish early stay neighbours (velocity zero)
+    w = scen.random_world(np.random.default_rng(9300), 6)
+    cases["m6_mix"] = run_case(w, [RVO, NC, ST, RVO, NC, RVO], U, homogeneous=True, coop=[0.5, 1, 1, 0.5, 1, 0.8])
+    blk = np.array([[-3, 0, 3, 0, 1.0, 0.5], [0, 0.2, 5, 5, 1.0, 0.5], [3, 0.1, -3, 0.1, 1.0, 0.4], [0.1, -4, 0.2, 4, 1.2, 0.3]])
+    cases["m4_static_block"] = run_case(blk, [RVO, ST, RVO, NC], U, homogeneous=True, coop=0.5)
+    # a crowd in a small square: linearProgram3 (infeasible LP2), collisions and time-outs among RVO agents
+    rr = np.random.default_rng(9400)
+    crowd = np.zeros((8, 6))
+    crowd[:, 0:2] = rr.uniform(-2.2, 2.2, (8, 2))
+    for i in range(8):
+        while min([np.hypot(*(crowd[i, 0:2] - crowd[j, 0:2])) for j in range(i)] + [9]) < 1.05:
+            crowd[i, 0:2] = rr.uniform(-2.2, 2.2, 2)
+    crowd[:, 2:4] = -crowd[:, 0:2] + rr.uniform(-0.5, 0.5, (8, 2))
+    crowd[:, 4] = rr.uniform(0.6, 1.4, 8)
+    crowd[:, 5] = rr.uniform(0.3, 0.5, 8)
+    cases["m8_crowd"] = run_case(crowd, RVO, U, homogeneous=True, coop=0.5, max_steps=260)
+    # 20 agents: maxNeighbors = MAX_NUM_AGENTS_IN_ENVIRONMENT = 20 (RVOPolicy.py:15)
+    w = scen.random_world(np.random.default_rng(9500), 20)
+    cases["m20_w0"] = run_case(w, RVO, U, homogeneous=True, coop=0.5, m_max=20, max_steps=120)
+    # rectangles: addObstacle at every call, processObstacles only at the first (RVOPolicy.py:45,56-57; Q21)
+    ig_obst = [(2, 2, 10, 10), (-10, 2, -2, 10), (2, -10, 10, -2), (-10, -10, -2, -2)]  # test_cases.py:3219-3223
+    corridor = np.array([[-5, 0, 12, 0, 1.0, 0.5], [0, 0, -12, 0.3, 1.0, 0.5], [5, 0.5, 0.4, 12, 1.0, 0.5],
+                         [0.3, -6, -8, 0.2, 1.0, 0.4]])
+    cases["obst_corridor"] = run_case(corridor, RVO, U, obstacles=ig_obst, laser=True, homogeneous=True, coop=0.5,
+                                      max_steps=200)
+    ro = np.random.default_rng(9600)
+    for wi in range(2):
+        obst = []
+        for _ in range(ro.integers(2, 5)):
+            cx, cy = ro.uniform(-6, 6, 2)
+            hw, hh = ro.uniform(0.4, 1.6, 2)
+            obst.append((round(cx - hw, 2), round(cy - hh, 2), round(cx + hw, 2), round(cy + hh, 2)))
+        w = scen.random_world(np.random.default_rng(9700 + wi), 5)
+        # keep starts and goals outside the rectangles (+ clearance)
+        for i in range(5):
+            for c in (0, 2):
+                while any(o[0] - 0.8 < w[i, c] < o[2] + 0.8 and o[1] - 0.8 < w[i, c + 1] < o[3] + 0.8 for o in obst):
+                    w[i, c:c + 2] = ro.uniform(-8, 8, 2)
+        cases["obst_rand_w%d" % wi] = run_case(w, [RVO, RVO, NC, RVO, RVO], U, obstacles=obst, laser=True,
+                                               homogeneous=True, coop=0.5, max_steps=200)
+    save("rvo_episodes", cases)
+
+
+def ga3c_episodes():
+    """UNMODIFIED reference episodes with GA3CCADRLPolicy agents whose TensorFlow network is the delegating stand-in
+    (ga3c_standin.py -> oracle/ga3c_ref.py): pins GA3CCADRLPolicy.find_next_action (:34-43) - state vector -> predict_p
+    -> argmax -> Actions table (network.py:8-17) -> pref_speed scaling - inside an episode.  The network arithmetic is
+    the oracle's numpy restatement."""
+    U, NC, ST, RVO, GA = scen.DYN_UNICYCLE, scen.POLICY_NONCOOP, scen.POLICY_STATIC, scen.POLICY_RVO, scen.POLICY_GA3C
+    cases = {}
+    w = scen.random_world(np.random.default_rng(8100), 4)
+    cases["m4_all_ga3c"] = run_case(w, GA, U, homogeneous=True, max_steps=200)
+    w = scen.random_world(np.random.default_rng(8200), 10)
+    cases["m10_ego_ga3c_rvo"] = run_case(w, [GA] + [RVO] * 9, U, homogeneous=False, coop=0.5, max_steps=200)
+    w = scen.random_world(np.random.default_rng(8300), 6)
+    cases["m6_mix"] = run_case(w, [GA, NC, GA, ST, NC, GA], U, homogeneous=True, max_steps=200)
+    with rh.quiet():
+        P2 = tc.preset_testCases(2)
+    cases["m2_swap"] = run_case(P2[0], GA, U, homogeneous=True, max_steps=200)
+    save("ga3c_episodes", cases)
+
+
 def scenario_statistics(n_worlds=400, n_agents=10):
     """Scenarios drawn by the reference's own train_agents_random_positions (test_cases.py:1362-1463), seeded with
     np.random.seed(k) / random.seed(k) by the function itself.  The third-party rvo2 simulator is absent, so its
@@ -622,8 +786,14 @@ if __name__ == "__main__":
         adapters()
     elif "--ig-only" in only:
         ig_primitives()
+    elif "--rvo-only" in only:
+        rvo_episodes()
+    elif "--ga3c-episodes-only" in only:
+        ga3c_episodes()
     else:  # the whole recipe, end to end
         main()
+        rvo_episodes()
+        ga3c_episodes()
         ig_primitives()
         ga3c_states()
         dmcts_reference()

@@ -25,7 +25,7 @@ def load_cases(group):
 
 def all_groups():
     return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLD, "*.npz"))
-                  if not os.path.basename(p).startswith(("ig_", "ga3c", "scenario_", "adapters")))  # episode fixtures only
+                  if not os.path.basename(p).startswith(("ig_", "ga3c_states", "scenario_", "adapters")))  # episode fixtures only
 
 
 def game_over_mode(cfg):
@@ -117,8 +117,9 @@ def replay(case, make_env, ftol=1e-12, oas_tol=1e-12, laser_tol=1e-12, check=Non
     a6p[M:, 5] = 0.1
     a6p[M:, 0] = 1e3 + np.arange(m_max - M)  # parked far away; inactive anyway
     a6p[M:, 2] = 2e3
+    coop = pad(case["coop"], 1.0)[None] if "coop" in case else None  # Agent.cooperation_coef (agent.py:10,103): RVO only
     env.set_scenario(a6p[None], pad(case["policy_id"])[None], pad(case["dynamics_id"])[None],
-                     heading0=pad(case["heading0"])[None], n_agents=[M],
+                     heading0=pad(case["heading0"])[None], n_agents=[M], coop=coop,
                      obstacles=obst[None] if len(obst) else None, n_obst=[len(obst)] if len(obst) else None)
     env.reset()
     T = case["pos"].shape[0] - 1

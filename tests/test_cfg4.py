@@ -151,3 +151,28 @@ def test_fused_laserscan_shortcut_with_rectangles_leaving_the_map():
         assert torch.equal(c.env.obs_laser, full), t
         seen += int((full > 0).sum())
     assert seen > 0
+
+
+def test_laserscan_on_a_handle_without_rectangles_reads_zero():
+    """laserscan=True with max_obstacles=0 runs the free-space kernels, which carry no scan code: the C ABI must still fill
+    the caller's buffers - every beam of an empty map reads 0.0 (LaserScanSensor.py:27-58) - in step, step_autoreset and
+    every slice of a rollout (the buffers are poisoned first: torch.empty rollouts would otherwise return garbage)."""
+    import torch
+    N, M, T = 8, 4, 12
+    a6 = scen.random_worlds_fast(N, M, seed=3)
+    e = _hip(N=N, M=M, max_obstacles=0, game_over_mode=1, laserscan=True)
+    e.set_scenario(a6, scen.POLICY_NONCOOP, scen.DYN_UNICYCLE)
+    e.env.obs_laser.fill_(7.0)
+    e.reset()
+    assert float(e.env.obs_laser.abs().max()) == 0.0
+    e.env.obs_laser.fill_(7.0)
+    e.env.step()
+    assert float(e.env.obs_laser.abs().max()) == 0.0
+    e.env.obs_laser.fill_(7.0)
+    e.env.step(auto_reset=True)
+    assert float(e.env.obs_laser.abs().max()) == 0.0
+    buf = e.env.alloc_rollout(T)
+    buf["laserscan"].fill_(7.0)
+    traj = e.env.rollout(T, auto_reset=True, out=buf)
+    torch.cuda.synchronize()
+    assert float(traj["laserscan"].abs().max()) == 0.0
