@@ -98,5 +98,30 @@ def build(force=False, verbose=False, extra=(), jobs=None):
     return LIB
 
 
+def build_variant(tag, extra=(), verbose=False):
+    """Diagnostic library csrc/libcagym_hip_<tag>.so: ONE translation unit (-DCAGYM_MONOLITHIC: the trace buffers are
+    device globals shared by the C ABI's debug hooks and the kernels) compiled with the extra flags, e.g.
+    build_variant("wavetrace", ["-DCAGYM_WAVETRACE"]).  Used by tools/*.py; never the shipped library."""
+    lib = os.path.join(CSRC, "libcagym_hip_%s.so" % tag)
+    os.makedirs(OBJ, exist_ok=True)
+    obj = os.path.join(OBJ, "mono_%s.o" % tag)
+    d = _digest("cagym_api.hip", ["-DCAGYM_MONOLITHIC"] + list(extra), HEADERS + ["cagym_k3_tu.hip", "cagym_k3_all.inc"], [])
+    stamp = obj + ".sha"
+    if not (os.path.exists(lib) and os.path.exists(stamp) and open(stamp).read() == d):
+        hipcc = os.environ.get("HIPCC", "hipcc")
+        cmd = [hipcc, "--offload-arch=" + ARCH, "-c", "-DCAGYM_MONOLITHIC"] + list(extra) + FLAGS + ["-o", obj, os.path.join(CSRC, "cagym_api.hip")]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+        tl = _torch_lib_dir()
+        subprocess.check_call(["g++", "-shared", "-o", lib, obj, "-L" + tl, "-lamdhip64", "-Wl,-rpath," + tl])
+        with open(stamp, "w") as fh:
+            fh.write(d)
+    return lib
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[1] == "--variant":  # python build.py --variant <tag> [flags...]
+        print(build_variant(sys.argv[2], sys.argv[3:], verbose=True))
+        sys.exit(0)
     print(build(force="--force" in sys.argv, verbose=True))

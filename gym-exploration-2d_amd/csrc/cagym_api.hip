@@ -132,7 +132,7 @@ inline int n_wg2(const Env* e) {
 // obst: the OBST instantiation (worlds may hold rectangles); lines: RVO agents among them (obstacle half-plane rows)
 inline size_t lds3_bytes(const Env* e, bool obst, bool lines) {
     const int M = e->cfg.max_agents;
-    return cagym_lds3_bytes(M, cagym_as(M, wpw_spec(e)), spec2(e).nt, (obst && lines) ? 2 * e->cfg.max_obstacles : 0, obst ? 4 : 2);
+    return cagym_lds3_bytes(M, cagym_as(M, wpw_spec(e)), spec2(e).nt, (obst && lines) ? 2 * e->cfg.max_obstacles : 0, cagym_lpl3(spec2(e).mt, obst), obst);
 }
 inline bool has_map(const Env* e) { return e->cfg.max_obstacles > 0; }
 inline size_t scan_bytes(const Env* e) { return (size_t)e->cfg.n_worlds * e->cfg.max_agents * 16 * sizeof(float); }
@@ -140,7 +140,7 @@ inline size_t lds3_bytes(const Env* e) { return lds3_bytes(e, has_map(e), e->obs
 // LP group width of the handle's specialisation (run_steps3)
 inline int lp_group_width(const Env* e) {
     const int mt = spec2(e).mt;
-    return mt > 0 && mt <= 5 ? 4 : (mt > 0 && mt <= 10 ? CAGYM_GW10 : 16);
+    return cagym_gw3(mt);
 }
 
 inline int n_waves(const Env* e) {

@@ -79,11 +79,28 @@ __device__ unsigned long long g_wavetrace[CAGYM_WT_STEPS * CAGYM_WT_POINTS * 8];
 #define WAVETRACE(t, point) do { } while (0)
 #endif
 
+// Static instruction accounting (-DCAGYM_PMARK, tools/isa_phases.py): named comments in the ISA at the phase boundaries
+#ifdef CAGYM_PMARK
+#define PMARK(name) asm volatile("; PMARK " name)
+#else
+#define PMARK(name) do { } while (0)
+#endif
+
 #ifndef CAGYM_GW10
 #define CAGYM_GW10 8  // lanes per ORCA LP group when M <= 10 (nn <= 9 half-planes)
 #endif
 
 __host__ __device__ inline size_t a16(size_t x) { return (x + 15) & ~(size_t)15; }
+// LP group geometry of a specialisation (compile-time M = MT, 0 = run-time M): lanes per group, "more than GW + 1 half-planes
+// possible", and the group's scratch in units of GW float4 (orca_lp_upfront: 2 NL - 1 entries, NL = GW + 1 or 2 GW lines;
+// the OBST instantiation's orca_lp_group_n: 4 GW)
+__host__ __device__ constexpr int cagym_gw3(int MT) { return MT > 0 && MT <= 5 ? 4 : (MT > 0 && MT <= 10 ? CAGYM_GW10 : 16); }
+__host__ __device__ constexpr bool cagym_two3(int MT) { return !(MT > 0 && MT - 1 <= cagym_gw3(MT) + 1); }
+#ifdef CAGYM_LP_UPFRONT
+__host__ __device__ constexpr int cagym_lpl3(int MT, bool obst) { return obst ? 4 : (cagym_two3(MT) ? 4 : 3); }
+#else
+__host__ __device__ constexpr int cagym_lpl3(int MT, bool obst) { return obst ? 4 : 2; }
+#endif
 __host__ __device__ inline int cagym_mp(int M) { return (M + 3) & ~3; }
 
 // AS = agent slots per workgroup (worlds per workgroup x M, rounded up to 4); 64 when a full wave is used
@@ -172,7 +189,9 @@ struct Lds3 {
     float* lpr;    // [AS] maxSpeed of the ego (LP radius)
     int* lpk;      // [AS] compact list of the busy egos
     int* busy;     // [AS] some half-plane of the ego is violated by its LP start
-    float* dsq;      // [AS*MP]       squared centre distance ego->slot, fp32 as RVO2 (+inf = no such neighbour)
+    uint2* dsq;      // [AS*MP]       {slot, bits of the fp32 squared centre distance ego->slot as RVO2 computes it (+inf = no such
+                     //               neighbour)}: ONE 64-bit key per neighbour whose unsigned order is Agent::insertAgentNeighbor's
+                     //               (nearer first, ties by lower index; distances are >= 0, so float order = bit order)
     float4* sorted;  // [ko + M - 1][AS]  half-planes in solve order: rows < ko obstacle lines (ko = 2 rectangles' worth per
                      //                  rectangle, 0 without obstacles), rows ko + rank agent lines nearest-first
     float4* lp3;     // [lpl NT]      linearProgram3 scratch, lpl GW entries per LP group (lpl = 2, 4 with obstacles); the
@@ -185,12 +204,13 @@ struct Lds3 {
 __host__ __device__ inline size_t cagym_lds3_head(int AS) {
     return (size_t)20 * AS * 8 + AS * 8 + (size_t)6 * AS * 4 + 96 * 4 + 8 * 4 + (size_t)2 * AS * 8 + (size_t)3 * AS * 4;
 }
-// ko: rows of `sorted` reserved for obstacle lines; lpl: half-planes per lane of an LP group
-__host__ __device__ inline size_t cagym_lds3_bytes(int M, int AS, int NT, int ko = 0, int lpl = 2) {
+// ko: rows of `sorted` reserved for obstacle lines; lpl: LP scratch per group in units of GW float4 (cagym_lpl3); obst: the OBST
+// instantiation's extra arrays
+__host__ __device__ inline size_t cagym_lds3_bytes(int M, int AS, int NT, int ko, int lpl, bool obst) {
     const size_t MP = cagym_mp(M);
-    return a16(cagym_lds3_head(AS)) + a16(AS * MP * 4) + (size_t)(ko + M - 1) * AS * 16 + (size_t)lpl * NT * 16 + 2 * AS * MP * 8 + a16(AS * MP) +
+    return a16(cagym_lds3_head(AS)) + a16(AS * MP * 8) + (size_t)(ko + M - 1) * AS * 16 + (size_t)lpl * NT * 16 + 2 * AS * MP * 8 + a16(AS * MP) +
            (size_t)(AS / M) * (ko / 2) * 64 +  // staged rectangles: worlds x Kobs x 4 float4
-           (lpl == 4 ? (size_t)(NT / CAGYM_WAVE) * 512 + a16((size_t)ko * AS * 4) + (size_t)AS * 16 : 0);  // OBST: beam lists, coverage bits, wall prep
+           (obst ? (size_t)(NT / CAGYM_WAVE) * 512 + a16((size_t)ko * AS * 4) + (size_t)AS * 16 : 0);  // OBST: beam lists, coverage bits, wall prep
 }
 
 __device__ __forceinline__ Lds3 carve_lds3(unsigned char* smem, int M, int AS, int NT, int ko = 0, int lpl = 2) {
@@ -218,8 +238,8 @@ __device__ __forceinline__ Lds3 carve_lds3(unsigned char* smem, int M, int AS, i
     W.wnob = W.wsc + 32;
     W.flag = W.wnob + 32;
     unsigned char* u = smem + a16(cagym_lds3_head(AS));
-    W.dsq = reinterpret_cast<float*>(u);
-    u += a16(AS * MP * 4);
+    W.dsq = reinterpret_cast<uint2*>(u);
+    u += a16(AS * MP * 8);
     W.sorted = reinterpret_cast<float4*>(u);
     u += (size_t)(ko + M - 1) * AS * 16;
     W.lp3 = reinterpret_cast<float4*>(u);
@@ -535,39 +555,42 @@ __device__ __forceinline__ void pair_distances3(const CagymDev& D, const Lds3& W
     W.gap[hi * MP + slo] = INFINITY;
     W.keys[lo * MP + shi] = klo;
     W.keys[hi * MP + slo] = khi;
-    W.dsq[lo * MP + shi] = dq;
-    W.dsq[hi * MP + slo] = dq;
+    W.dsq[lo * MP + shi] = make_uint2((uint32_t)shi, __float_as_uint(dq));
+    W.dsq[hi * MP + slo] = make_uint2((uint32_t)slo, __float_as_uint(dq));
 }
 
-// rank of slot sl in ego a's row of squared distances: nearest first, ties by lower index (Agent::insertAgentNeighbor)
+// rank of slot sl in ego a's row of squared distances: nearest first, ties by lower index (Agent::insertAgentNeighbor).
+// The row holds one 64-bit key per slot, (distance bits << 32) | slot: "nearer, or as near with a lower index" is ONE unsigned
+// 64-bit comparison, and the count one add-with-carry per slot (two instructions per slot; the float version needed two
+// comparisons, an index test, the logic between them and the add).  The own slot and the padding hold +inf.
 template <int MT>
 __device__ __forceinline__ int neighbour_rank3(const Lds3& W, int a, int sl, float dq, int MP) {
-    const float4* row = reinterpret_cast<const float4*>(W.dsq + a * MP);
+    const uint4* row = reinterpret_cast<const uint4*>(W.dsq + a * MP);  // MP is a multiple of 4: 16-byte aligned pairs of keys
+    const unsigned long long me = ((unsigned long long)__float_as_uint(dq) << 32) | (unsigned)sl;
     int rank = 0;
-    constexpr int MPT = MT > 0 ? ((MT + 3) & ~3) : 0;
+    constexpr int MPT = MT > 0 ? ((MT + 1) & ~1) : 0;  // compile-time M: the keys beyond it are padding (+inf), never smaller
     if (MT > 0) {
 #pragma unroll
-        for (int l4 = 0; l4 < MPT; l4 += 4) {
-            const float4 v = row[l4 >> 2];
-            rank += (v.x < dq) || (v.x == dq && l4 + 0 < sl);
-            rank += (v.y < dq) || (v.y == dq && l4 + 1 < sl);
-            rank += (v.z < dq) || (v.z == dq && l4 + 2 < sl);
-            rank += (v.w < dq) || (v.w == dq && l4 + 3 < sl);
+        for (int l2 = 0; l2 < MPT; l2 += 2) {
+            const uint4 v = row[l2 >> 1];
+            rank += ((((unsigned long long)v.y << 32) | v.x) < me) ? 1 : 0;
+            rank += ((((unsigned long long)v.w << 32) | v.z) < me) ? 1 : 0;
         }
     } else {
-        for (int l4 = 0; l4 < MP; l4 += 4) {
-            const float4 v = row[l4 >> 2];
-            rank += (v.x < dq) || (v.x == dq && l4 + 0 < sl);
-            rank += (v.y < dq) || (v.y == dq && l4 + 1 < sl);
-            rank += (v.z < dq) || (v.z == dq && l4 + 2 < sl);
-            rank += (v.w < dq) || (v.w == dq && l4 + 3 < sl);
+        for (int l2 = 0; l2 < MP; l2 += 2) {
+            const uint4 v = row[l2 >> 1];
+            rank += ((((unsigned long long)v.y << 32) | v.x) < me) ? 1 : 0;
+            rank += ((((unsigned long long)v.w << 32) | v.z) < me) ? 1 : 0;
         }
     }
     return rank;
 }
 
 // ---- phase B body: ORCA half-planes of one unordered pair, ranked into both egos' nearest-first line lists -----------------
-template <int MT>
+// LAZY (free-space kernels): the half-planes are stored UNSORTED, row = the neighbour's slot with the ego's own slot skipped; the
+// LP group of an ego that turns out busy ranks them (lp_rank_lines3) - two thirds of the egos never need their lines, and
+// the two rank loops per pair lane were the largest part of this phase.  !LAZY (OBST kernels): ranked here, as in round 2.
+template <int MT, bool LAZY>
 __device__ __forceinline__ void half_planes3(const CagymDev& D, const Lds3& W, int p, int M, int MP, int AS, int ko) {
     const UPair q = upair_of<MT>(p, M);
     const int n = W.wn[q.wl];
@@ -579,27 +602,58 @@ __device__ __forceinline__ void half_planes3(const CagymDev& D, const Lds3& W, i
     const float vax = (float)W.tvx[a], vay = (float)W.tvy[a];
     const OrcaPair g = orca_pair((float)W.tpx[a], (float)W.tpy[a], vax, vay, (float)((1 + 15e-2) * W.tr[a]), (float)D.dt,
                                  W.tpx[b], W.tpy[b], W.tvx[b], W.tvy[b], W.tr[b]);
+    PMARK("hp_pair_done");
     if (on_a) {
         const float c = W.tcoop[a];
         const float4 ln = make_float4(vax + c * g.ux, vay + c * g.uy, g.zx, g.zy);
         const float2 s0 = W.lpc[a];
         if (detf(ln.z, ln.w, ln.x - s0.x, ln.y - s0.y) > 0.0f) W.busy[a] = 1;
-        const int rank = neighbour_rank3<MT>(W, a, q.j, g.d2, MP);
-        if (rank < D.maxnb) W.sorted[(ko + rank) * AS + a] = ln;
+        if (LAZY) {
+            W.sorted[(q.j < q.i ? q.j : q.j - 1) * AS + a] = ln;
+        } else {
+            const int rank = neighbour_rank3<MT>(W, a, q.j, g.d2, MP);
+            if (rank < D.maxnb) W.sorted[(ko + rank) * AS + a] = ln;
+        }
     }
     if (on_b) {
         const float c = W.tcoop[b];
         const float4 ln = make_float4((float)W.tvx[b] - c * g.ux, (float)W.tvy[b] - c * g.uy, -g.zx, -g.zy);
         const float2 s0 = W.lpc[b];
         if (detf(ln.z, ln.w, ln.x - s0.x, ln.y - s0.y) > 0.0f) W.busy[b] = 1;
-        const int rank = neighbour_rank3<MT>(W, b, q.i, g.d2, MP);
-        if (rank < D.maxnb) W.sorted[(ko + rank) * AS + b] = ln;
+        if (LAZY) {
+            W.sorted[(q.i < q.j ? q.i : q.i - 1) * AS + b] = ln;
+        } else {
+            const int rank = neighbour_rank3<MT>(W, b, q.i, g.d2, MP);
+            if (rank < D.maxnb) W.sorted[(ko + rank) * AS + b] = ln;
+        }
     }
+}
+
+// Lazy ranking (free-space kernels): the LP group of busy ego `a` (slot sl of a world of nw agents) turns its column of
+// unsorted half-planes (row q <-> neighbour slot q < sl ? q : q + 1) into nearest-first order IN PLACE: lane j takes the
+// candidates q = j and q = j + GW, counts each one's rank in the ego's row of squared distances (Agent::insertAgentNeighbor's
+// order: nearer first, ties by lower index) and stores it to row `rank` when that is below nn = min(nw - 1, maxNeighbors).
+// One wave: its LDS operations complete in program order, so every candidate is read before any row is overwritten.
+template <int MT, int GW>
+__device__ __forceinline__ void lp_rank_lines3(const Lds3& W, int a, int sl, int nw, int nn, int j, int M, int MP, int AS) {
+    const int q0 = j, q1 = j + GW;
+    const int o0 = q0 < sl ? q0 : q0 + 1, o1 = q1 < sl ? q1 : q1 + 1;
+    const bool e0 = q0 < M - 1 && o0 < nw, e1 = q1 < M - 1 && o1 < nw;
+    // (clamped addresses instead of conditional loads: a lane without a candidate reads row 0 and never uses it)
+    const float4 c0 = W.sorted[(e0 ? q0 : 0) * AS + a], c1 = W.sorted[(e1 ? q1 : 0) * AS + a];
+    const float d0 = __uint_as_float(W.dsq[a * MP + (e0 ? o0 : 0)].y), d1 = __uint_as_float(W.dsq[a * MP + (e1 ? o1 : 0)].y);
+    const int r0 = neighbour_rank3<MT>(W, a, o0, d0, MP);
+    int r1 = 0;
+    if (__ballot(e1) != 0ull) r1 = neighbour_rank3<MT>(W, a, o1, d1, MP);
+    asm volatile("" ::: "memory");  // all reads of the column stay ahead of its rewriting
+    if (e0 && r0 < nn) W.sorted[r0 * AS + a] = c0;
+    if (e1 && r1 < nn) W.sorted[r1 * AS + a] = c1;
 }
 
 // ---- one 64-row chunk of the OtherAgentsStates table (sensors/OtherAgentsStatesSensor.py:11-77), straight to HBM ----------
 __device__ __forceinline__ void oas_row3(const Lds3& W, float* oas_out, int p, int npairs, int M, int MP, int K, int wpw,
                                          int worlds_valid, uint32_t inv_m) {
+    PMARK("oas_begin");
     if (p >= npairs) return;
     const PairIdx q = pair_of(p, M, inv_m);
     if (q.j == q.sl || q.wl >= worlds_valid) return;
@@ -621,6 +675,7 @@ __device__ __forceinline__ void oas_row3(const Lds3& W, float* oas_out, int p, i
             before += (kk.y > kj) || (kk.y == kj && l2 + 1 > q.j);
         }
         row = before;
+        PMARK("oas_ranked");
         const int b = q.a - q.sl + q.j;
         const double dx = W.tpx[b] - W.tpx[q.a], dy = W.tpy[b] - W.tpy[q.a];
         const double prx = W.tprx[q.a], pry = W.tpry[q.a], orx = -pry, ory = prx;
@@ -636,6 +691,7 @@ __device__ __forceinline__ void oas_row3(const Lds3& W, float* oas_out, int p, i
         v[8] = (float)kj;
         v[9] = ST_POLICY(W.tst[b]) == CAGYM_POL_STATIC ? 1.f : 2.f;
     }
+    PMARK("oas_store");
     float2* r2 = reinterpret_cast<float2*>(my + row * 10);  // rows are 40 B: 8-byte aligned
 #pragma unroll
     for (int c = 0; c < 5; c++) r2[c] = make_float2(v[2 * c], v[2 * c + 1]);
@@ -809,12 +865,18 @@ template <int NT, int MT, int WPWT, bool AUTO_RESET, bool OBST>
 __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const float* ext, const CagymOut& out, int n_steps,
                                   bool any_rvo) {
     constexpr int NWAVES = NT / CAGYM_WAVE;
-    constexpr int GW = MT > 0 && MT <= 5 ? 4 : (MT > 0 && MT <= 10 ? CAGYM_GW10 : 16), NG = NT / GW, NGW = CAGYM_WAVE / GW;
-    constexpr bool TWO = !(MT > 0 && MT - 1 <= GW + 1);  // more than GW + 1 half-planes possible: two per lane of an LP group
+    constexpr int GW = cagym_gw3(MT), NG = NT / GW, NGW = CAGYM_WAVE / GW;
+    constexpr bool TWO = cagym_two3(MT);  // more than GW + 1 half-planes possible
+    constexpr int NL = TWO ? 2 * GW : GW + 1;  // compile-time bound on the half-planes of one ego (free space)
     const int M = MT ? MT : D.M, K = M - 1, MP = cagym_mp(M);
     const int AS = cagym_as(M, WPWT);
     const int ko = OBST ? D.ko : 0;  // 2 * Kobs: an agent outside a rectangle sees at most 2 of its edges from their right side
-    constexpr int LPL = OBST ? 4 : 2;
+    constexpr int LPL = cagym_lpl3(MT, OBST);
+#ifdef CAGYM_LP_UPFRONT  // measured alternative (cagym_orca.h: orca_lp_upfront): lazy ranking + all linearProgram1 results up front
+    constexpr bool LAZY_RANK = true;
+#else
+    constexpr bool LAZY_RANK = false;
+#endif
     const Lds3 W = carve_lds3(smem, M, AS, NT, ko, LPL);
     LaneCtx C = make_ctx2(D, M, WPWT ? WPWT : CAGYM_WAVE / M);
     const uint32_t inv_m = (uint32_t)(0x100000000ull / (uint32_t)M) + 1u;
@@ -845,12 +907,12 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
                 W.wsc[C.wl] = C.valid ? (int)(((long long)C.world + (long long)C.episode * D.N) % D.S) : 0;
             }
             // constant entries of the distance / key rows: own slot and the padding
-            W.dsq[tid * MP + C.slot] = INFINITY;
+            W.dsq[tid * MP + C.slot] = make_uint2((uint32_t)C.slot, 0x7f800000u);
             W.hit[tid * MP + C.slot] = 0;
             W.gap[tid * MP + C.slot] = INFINITY;
             W.keys[tid * MP + C.slot] = -INFINITY;
             for (int l = M; l < MP; l++) {
-                W.dsq[tid * MP + l] = INFINITY;
+                W.dsq[tid * MP + l] = make_uint2((uint32_t)l, 0x7f800000u);
                 W.hit[tid * MP + l] = 0;
                 W.gap[tid * MP + l] = INFINITY;
                 W.keys[tid * MP + l] = -INFINITY;
@@ -871,7 +933,7 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
         if (any_rvo) {
             for (int p = tid; p < nup; p += NT) pair_distances3<MT>(D, W, p, M, MP);
             __syncthreads();
-            for (int p = tid; p < nup; p += NT) half_planes3<MT>(D, W, p, M, MP, AS, ko);
+            for (int p = tid; p < nup; p += NT) half_planes3<MT, LAZY_RANK && !OBST>(D, W, p, M, MP, AS, ko);
         }
         __syncthreads();
     }
@@ -897,6 +959,7 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
         else __builtin_amdgcn_s_setprio(1);
 #endif
         WAVETRACE(t, 0);
+        PMARK("C_begin");
         // ---- phase C: linearProgram2/3 of every busy ego on a GW-lane group (first waves) ------------------------------
         int lp_waves = 0;
         if (any_rvo) {
@@ -918,6 +981,7 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
 #ifdef CAGYM_STAMPS
             int dbg[3] = {0, 0, 0};
 #endif
+            PMARK("C_lp_loop");
             for (int base = 0; base < cnt; base += NG) {
                 const int idx = base + g;
                 if (idx < cnt) {
@@ -937,14 +1001,18 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
                         else
                             orca_lp_group_n<GW, 2>(W.sorted, W.lp3 + LPL * (tid & ~(GW - 1)), a, j, nol, nn, ko, rad, pv.x, pv.y, vx, vy, AS, &W.flag[3]);
                     } else {
-#ifdef CAGYM_STAMPS
-                        orca_lp_group<GW, TWO, (MT > 0 ? MT - 1 : 0)>(W.sorted, W.lp3 + 2 * (tid & ~(GW - 1)), a, j, nn, rad, pv.x, pv.y, vx, vy, AS, &W.flag[3], dbg);
+#ifdef CAGYM_LP_UPFRONT
+                        // the ego's unsorted half-planes -> nearest-first (lazily: only busy egos get here), then all
+                        // linearProgram1 results up front and the find-first-set walk (cagym_orca.h)
+                        lp_rank_lines3<MT, GW>(W, a, a - wl * M, n, nn, j, M, MP, AS);
+                        const float2 s0 = W.lpc[a];
+                        orca_lp_upfront<GW, NL>(W.sorted + a, AS, W.lp3 + LPL * (tid & ~(GW - 1)), j, nn, rad, pv.x, pv.y, s0.x, s0.y, vx, vy, &W.flag[3]);
 #else
 #ifdef CAGYM_WAVETRACE
-                        orca_lp_group<GW, TWO, (MT > 0 ? MT - 1 : 0)>(W.sorted, W.lp3 + 2 * (tid & ~(GW - 1)), a, j, nn, rad, pv.x, pv.y, vx, vy, AS, &W.flag[3], nullptr,
+                        orca_lp_group<GW, TWO, (MT > 0 ? MT - 1 : 0)>(W.sorted, W.lp3 + LPL * (tid & ~(GW - 1)), a, j, nn, rad, pv.x, pv.y, vx, vy, AS, &W.flag[3], nullptr,
                                                                   ((int)blockIdx.x == g_wt_wg && t < CAGYM_WT_STEPS && base == 0) ? g_wavetrace + (size_t)t * CAGYM_WT_POINTS * 8 : nullptr);
 #else
-                        orca_lp_group<GW, TWO, (MT > 0 ? MT - 1 : 0)>(W.sorted, W.lp3 + 2 * (tid & ~(GW - 1)), a, j, nn, rad, pv.x, pv.y, vx, vy, AS, &W.flag[3]);
+                        orca_lp_group<GW, TWO, (MT > 0 ? MT - 1 : 0)>(W.sorted, W.lp3 + LPL * (tid & ~(GW - 1)), a, j, nn, rad, pv.x, pv.y, vx, vy, AS, &W.flag[3]);
 #endif
 #endif
                     }
@@ -961,12 +1029,14 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
             }
 #endif
             WAVETRACE(t, 2);
+            PMARK("C_lp_done");
             // a wave that solved programs publishes them: LDS operations of one wave complete in order, the release
             // makes the compiler keep that order
             if (__builtin_amdgcn_readfirstlane((int)(__ballot(worked) != 0ull)) && (tid & (CAGYM_WAVE - 1)) == 0)
                 __hip_atomic_fetch_add(&W.flag[2], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         STAMP(1);
+        PMARK("D_begin");
         // ---- phase D: wave 0 = S1 (_take_action, env.py:287-340) in registers; the other waves = OAS rows of step t-1 ------
         Agent A;
         bool moved = false;
@@ -978,6 +1048,7 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
             }
             STAMP(2);
             WAVETRACE(t, 3);
+            PMARK("D_s1_begin");
             if (s1_lane) {
                 A = lds3_load_agent(W, tid);
                 float a0 = 0.f, a1 = 0.f;
@@ -1009,12 +1080,14 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
                 WAVETRACE(t, 15);
                 moved = take_action<false>(A, a0, a1, D.dt, &hint);
             }
+            PMARK("D_s1_end");
             STAMP(3);
             WAVETRACE(t, 4);
         } else if (t > 0) {
 #ifndef CAGYM_NO_LAG_PRIORITY
             __builtin_amdgcn_s_setprio(0);
 #endif
+            PMARK("D_rows_begin");
             observation_chunks3<OBST>(D, W, o_prev, npairs, M, MP, K, C.wpw, C.worlds_valid, inv_m, ko);
 #ifndef CAGYM_NO_LAG_PRIORITY
             if (lagging) __builtin_amdgcn_s_setprio(3);
@@ -1022,6 +1095,7 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
 #endif
             WAVETRACE(t, 4);
         }
+        PMARK("D_end_barrierX");
         __syncthreads();  // rows of step t-1 are out: the moved state may replace the old one
         WAVETRACE(t, 5);
         if (s1_lane) {
@@ -1035,6 +1109,7 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
         __syncthreads();
         STAMP(4);
         WAVETRACE(t, 6);
+        PMARK("A_begin");
         // ---- phase A: pair distances, collision tests, OAS sort keys, fp32 squared distances; the last wave first prepares
         //      the next step's LP inputs (Dynamics.update_ego_frame waits for phase B: nothing before the rows needs it) -------
         if (tid >= NT - CAGYM_WAVE) {
@@ -1043,7 +1118,9 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
             WAVETRACE(t, 7);
         }
         if (OBST && D.map_bits && agent_lane) wall_prep3(D, W, tid, ko, inv_m, M);  // wave 0, beside the last wave's LP inputs
+        PMARK("A_pairs_begin");
         for (int p = tid; p < nup; p += NT) pair_distances3<MT>(D, W, p, M, MP);
+        PMARK("A_pairs_end");
         WAVETRACE(t, 8);
         const bool obst_lines = OBST && ko > 0 && any_rvo && t + 1 < n_steps;
         if (OBST && (D.map_bits || obst_lines)) __syncthreads();
@@ -1052,6 +1129,7 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
         __syncthreads();
         STAMP(5);
         WAVETRACE(t, 9);
+        PMARK("B_begin");
         // ---- phase B: wave 0 = S2 (_compute_rewards env.py:502-567, _check_which_agents_done :711-738, auto-reset);
         //      waves 1.. = ORCA half-planes of step t+1 (wave 0 takes the pairs beyond their lanes afterwards) ----------------
         const bool more = t + 1 < n_steps;
@@ -1145,16 +1223,20 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
                     W.tdg[tid] = E.dg; W.the[tid] = E.he; W.tprx[tid] = prx; W.tpry[tid] = pry;
                 }
             }
+            PMARK("B_s2_end");
             // a last partial round of at most one wave of pairs is wave 0's (it is done with S2 before the others finish)
-            if (any_rvo && more && tail_pairs <= CAGYM_WAVE && tid < tail_pairs) half_planes3<MT>(D, W, full_pairs + tid, M, MP, AS, ko);
+            if (any_rvo && more && tail_pairs <= CAGYM_WAVE && tid < tail_pairs) half_planes3<MT, LAZY_RANK && !OBST>(D, W, full_pairs + tid, M, MP, AS, ko);
         } else if (any_rvo && more) {
             const int lim = tail_pairs <= CAGYM_WAVE ? full_pairs : nup;
-            for (int p = tid - CAGYM_WAVE; p < lim; p += NT - CAGYM_WAVE) half_planes3<MT>(D, W, p, M, MP, AS, ko);
+            PMARK("B_hp_begin");
+            for (int p = tid - CAGYM_WAVE; p < lim; p += NT - CAGYM_WAVE) half_planes3<MT, LAZY_RANK && !OBST>(D, W, p, M, MP, AS, ko);
         }
+        PMARK("B_end");
         WAVETRACE(t, 10);
         __syncthreads();
         STAMP(6);
         WAVETRACE(t, 11);
+        PMARK("R_begin");
         // ---- rare: a world restarted on its next scenario -> everything derived from the old episode is rebuilt -------------
         if (AUTO_RESET && W.flag[0]) {
             if (OBST && ko > 0) {  // the restarted worlds' rectangles (also behind the last step: the epilogue's scan uses them)
@@ -1176,9 +1258,10 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
             }
             __syncthreads();
             if (any_rvo && more)
-                for (int p = tid; p < nup; p += NT) half_planes3<MT>(D, W, p, M, MP, AS, ko);
+                for (int p = tid; p < nup; p += NT) half_planes3<MT, LAZY_RANK && !OBST>(D, W, p, M, MP, AS, ko);
             __syncthreads();
         }
+        PMARK("step_end");
         STAMP(7);
         WAVETRACE(t, 12);
         WGTRACE(2 + t);

@@ -7,11 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 b = importlib.import_module("gym-exploration-2d_amd.build")
 import torch
-tl = os.path.join(os.path.dirname(torch.__file__), "lib")
-lib = os.path.join(b.CSRC, "libcagym_hip_stamps.so")
-obj = os.path.join(b.CSRC, "cagym_api_stamps.o")
-subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-c", "-DCAGYM_STAMPS"] + b.FLAGS + ["-o", obj, os.path.join(b.CSRC, "cagym_api.hip")])
-subprocess.check_call(["g++", "-shared", "-o", lib, obj, "-L" + tl, "-lamdhip64", "-Wl,-rpath," + tl])
+lib = b.build_variant("stamps", ["-DCAGYM_STAMPS"])
 os.environ["CAGYM_LIB"] = lib
 scen = importlib.import_module("gym-exploration-2d_amd.scenarios")
 B = importlib.import_module("gym-exploration-2d_amd.batched_env").BatchedCollisionAvoidanceEnv

@@ -8,12 +8,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 b = importlib.import_module("gym-exploration-2d_amd.build")
 import torch
-LIB = os.path.join(b.CSRC, "libcagym_hip_wavetrace.so")
 if "--child" not in sys.argv:
-    tl = os.path.join(os.path.dirname(torch.__file__), "lib")
-    obj = os.path.join(b.CSRC, "cagym_api_wavetrace.o")
-    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-c", "-DCAGYM_WAVETRACE"] + os.environ.get("WT_DEFS", "").split() + b.FLAGS + ["-o", obj, os.path.join(b.CSRC, "cagym_api.hip")])
-    subprocess.check_call(["g++", "-shared", "-o", LIB, obj, "-L" + tl, "-lamdhip64", "-Wl,-rpath," + tl])
+    # one monolithic diagnostic unit (build.build_variant caches it: build it in the development container, the GPU box reuses it)
+    LIB = b.build_variant("wavetrace", ["-DCAGYM_WAVETRACE"] + os.environ.get("WT_DEFS", "").split())
     sys.exit(subprocess.call([sys.executable, os.path.abspath(__file__), "--child"], env=dict(os.environ, CAGYM_LIB=LIB)))
 scen = importlib.import_module("gym-exploration-2d_amd.scenarios")
 B = importlib.import_module("gym-exploration-2d_amd.batched_env").BatchedCollisionAvoidanceEnv
@@ -43,7 +40,7 @@ for rep in range(12):
 A = np.concatenate(acc)  # [steps, points, waves] ticks since the first wave entered the step
 names = ["step top", "busy list built", "own LP groups done", "wave 0: all LP waves done", "S1 done (w0) / rows done (others)", "after barrier X",
          "after publish + barrier Y", "last wave: ego frame + LP inputs done", "pair distances done", "after barrier A",
-         "S2 done (w0) / half-planes done (others)", "after barrier B", "step end", "LP: lines loaded, start point", "LP: linearProgram2 done", "S1: action chosen (orca_post)"]
+         "S2 done (w0) / half-planes done (others)", "after barrier B", "step end", "LP: lines ranked, own lines loaded", "LP: first program (linearProgram2) done", "S1: action chosen (orca_post)"]
 print("%d worlds, workgroup 7, median over %d steps; ticks since the step's first wave started (0 = point not reached by that wave)" % (N, A.shape[0]))
 print("%-46s %9s %9s %9s %9s" % ("point", "wave 0", "wave 1", "wave 2", "wave 3"))
 for k, n in enumerate(names):
