@@ -9,12 +9,18 @@ tensors to HBM slice t of a trajectory buffer).
 
 Timing (repeats, median): after --warmup untimed steps the block of EXACTLY --steps steps is timed
 `repeats` times, each time bracketed by barrier + torch.cuda.synchronize() on both sides and max-reduced over ranks;
-`ms_per_step` / `value` are the MEDIAN block (min / max beside it).
+`ms_per_step` / `value` are the MEDIAN block (min / max beside it).  Short blocks are repeated until the timed blocks
+cover at least 2 s whatever --steps is (the driver's 20-step block is 0.2 ms: ~9000 blocks).  ONE clock: `value`,
+`ms_per_step` and `roofline.achieved` / `frac` all come from the wall-clock median block; the HIP-event duration of the
+same blocks is printed beside it as `roofline.launch_ms_hip_events` / `frac_hip_events`.
 
 Multi-GPU: `python bench.py --gpus N` with no RANK in the environment starts N one-GPU ranks itself
 (torch.distributed.run, before anything touches the GPU in this process); under a launcher (RANK set) it is one rank.
 Worlds are independent, each rank owns its own 4096 worlds (weak scaling); the only collective is the RCCL all-gather
-of per-world episode statistics, issued once per rollout launch on a side stream.
+of per-world episode statistics (24-byte records packed by one kernel, cagym_pack_episode_stats) on a side stream.  The
+counters are cumulative, so it is issued once every G timed blocks, G chosen from its measured duration so that it costs
+at most 1 % of the timed time; the main stream never waits for the side stream inside a block (the bracketing
+synchronize at the block's end is the only join).
 
 Other rows of SURVEY 8(d): --config cfg2 (4096 x 4 NonCooperative), cfg4 (8192 x 10: GA3C-CADRL agent 0 + 9 RVO among
 rectangles, LaserScan), cfg5 (2048 x 20 information-gain env part + planner primitives).
@@ -166,11 +172,14 @@ def main():
     side = torch.cuda.Stream(device=device) if world_size > 1 else None
     gathered = None
 
-    def gather_stats(env):
+    stats_state = {"every": 1, "block": 0, "collective_ms": None}
+
+    def gather_stats(env, force=False):
+        """Episode-statistics all-gather (multi-GPU only): one pack kernel on the main stream, the collective on the side
+        stream; issued in one of every stats_state["every"] timed blocks (cumulative counters: nothing is lost)."""
         nonlocal gathered
-        if world_size > 1:
-            # episode-stats all-gather on a side stream, overlapping the next launch
-            local = stats_mod.pack_episode_stats(env.episode_stats())
+        if world_size > 1 and (force or stats_state["block"] % stats_state["every"] == 0):
+            local = env.packed_episode_stats()
             side.wait_stream(torch.cuda.current_stream(device))
             local.record_stream(side)  # allocated on the main stream, read by the collective on the side stream
             with torch.cuda.stream(side):
@@ -206,9 +215,7 @@ def main():
                     env.rollout(k, auto_reset=True, out=traj)
                     launches += 1
                 done += k
-                gather_stats(env)
-            if side is not None:
-                torch.cuda.current_stream(device).wait_stream(side)
+            gather_stats(env)  # at most once per block; joined by the bracketing synchronize, never by the main stream
             return launches
     elif args.config == "cfg4":
         # agent 0 GA3C-CADRL (state kernel + fused forward kernel per step) + 9 RVO agents among 2-10 rectangles,
@@ -236,8 +243,6 @@ def main():
                 ga3c.act(ext)
                 env.step(ext, auto_reset=True)
             gather_stats(env)
-            if side is not None:
-                torch.cuda.current_stream(device).wait_stream(side)
             return n_steps
 
         def cfg4_extra():
@@ -271,8 +276,8 @@ def main():
         ext[:, :3, 0] = 2.0
         balg = B_STATE + B_OAS19
         workload = ("%d worlds x %d agents%s, env part: 3 information-gain agents (external (v, omega), FirstOrderDynamics), 2 static "
-                    "targets, 15 NonCooperative, rectangles, OtherAgentsStates [19, 10] (BASELINE configs[4]); the planner part is "
-                    "reported as visibility queries/s and roll-outs/s" % (N, M, " on this rank" if world_size > 1 else ""))
+                    "targets, 15 NonCooperative, rectangles, OtherAgentsStates [19, 10] (BASELINE configs[4]); `value` is the env part, the whole "
+                    "step with the belief update and the Dec-MCTS planning step at the experiment's budget is `cfg5.whole_loop_env_steps_per_s`" % (N, M, " on this rank" if world_size > 1 else ""))
         launch_mode = "cagym_step_autoreset per step"
         kernel_name = env.kernel_name(rollout=False, auto_reset=True)
 
@@ -280,16 +285,36 @@ def main():
             for _ in range(n_steps):
                 env.step(ext, auto_reset=True)
             gather_stats(env)
-            if side is not None:
-                torch.cuda.current_stream(device).wait_stream(side)
             return n_steps
 
         def cfg5_extra():
+            """The WHOLE cfg5 step as the reference runs it (env.py:342-379 _take_action_dmcts + experiments/src/dmcts.py:50-95):
+            belief update from the IG robots' poses (targetMap.update), team MI reward, one Dec-MCTS planning step at the
+            experiment's budget (Ntree 30, Nsims 10, horizon 4, xdt 5, Ncycles 5, 3 robots: cagym_dmcts_plan), then the env
+            step with the planned (v, omega).  Timed with synchronize brackets around `loop_steps` whole steps; the parts
+            are timed again in their own loops.  Planner primitives (bare kernels) beside it."""
+            dmm = importlib.import_module("gym-exploration-2d_amd.dmcts")
             ig = IG(env)
-            rng = np.random.default_rng(0)
-            Q = N * 32
-            poses = torch.from_numpy(np.concatenate([rng.uniform(-12, 12, (Q, 2)), rng.uniform(-np.pi, np.pi, (Q, 1))], 1)).to(device)
-            world = torch.arange(Q, device=device, dtype=torch.int32) % N
+            R = 3
+            planner = dmm.DeviceDecMCTSPlanner(ig, R, radius=0.5, Ntree=30, Nsims=10, horizon=4, c_p=1.0, gamma=0.95, Ncycles=5, seed=1)
+            wd = torch.arange(N, dtype=torch.int32, device=device)
+            det = torch.zeros((N, R, 1, 2), dtype=torch.float64, device=device)
+            nd = torch.zeros((N, R), dtype=torch.int32, device=device)
+            cum = torch.zeros(N, dtype=torch.float64, device=device)
+            st = env.state()
+
+            def poses_now():
+                return torch.stack([st["pos_x"][:, :R], st["pos_y"][:, :R], st["heading"][:, :R]], dim=2).contiguous()
+
+            def whole_step():
+                nonlocal cum
+                p = poses_now()
+                obs = ig.update_belief(p, det, nd)   # detections: none (static targets are farther than 5 m almost always; Q24)
+                cum = cum + ig.mi_reward(obs, wd)
+                actions, _ = planner.plan(p)
+                ext[:, :R] = actions.float()
+                env.step(ext, auto_reset=True)
+                ig.reset_belief(env.game_over)       # a restarted world starts from the prior again (targetMap.__init__)
 
             def loop(fn, reps=10):
                 fn()
@@ -299,11 +324,31 @@ def main():
                     fn()
                 torch.cuda.synchronize(device)
                 return (time.perf_counter() - t0) / reps
+            loop_steps = 6
+            t_whole = loop(whole_step, reps=loop_steps)
+            p0 = poses_now()
+            t_plan = loop(lambda: planner.plan(p0), reps=3)
+            t_bel = loop(lambda: ig.mi_reward(ig.update_belief(p0, det, nd), wd), reps=10)
+            t_env = loop(lambda: env.step(ext, auto_reset=True), reps=50)
+            # planner primitives (bare kernels; every argument already on the device)
+            rng = np.random.default_rng(0)
+            Q = N * 32
+            poses = torch.from_numpy(np.concatenate([rng.uniform(-12, 12, (Q, 2)), rng.uniform(-np.pi, np.pi, (Q, 1))], 1)).to(device)
+            world = torch.arange(Q, device=device, dtype=torch.int32) % N
             t_vis = loop(lambda: ig.visible_cells(poses, world))
             Qr, nsims, H = N * 3, 10, 4  # experiments/src/dmcts.py budget: Nsims 10, horizon 4, xdt 5
             zeros = torch.zeros((Qr, 60), dtype=torch.int64, device=device)
-            t_ro = loop(lambda: ig.rollouts(poses[:Qr], zeros, zeros, world[:Qr], torch.full((Qr,), H), torch.full((Qr,), 0.5), nsims, 7))
-            return {"visibility_queries_per_s": Q / t_vis, "rollouts_per_s_horizon4": Qr * nsims / t_ro,
+            nst = torch.full((Qr,), H, dtype=torch.int32, device=device)
+            rad = torch.full((Qr,), 0.5, dtype=torch.float64, device=device)
+            pr, wr = poses[:Qr].contiguous(), world[:Qr].contiguous()
+            t_ro = loop(lambda: ig.rollouts(pr, zeros, zeros, wr, nst, rad, nsims, 7, max_steps=H))
+            grows = R * 5 * 30
+            return {"whole_step_ms": 1e3 * t_whole, "whole_loop_env_steps_per_s": N / t_whole, "loop_steps_timed": loop_steps,
+                    "planner_ms_per_step": 1e3 * t_plan, "belief_update_and_reward_ms": 1e3 * t_bel, "env_step_ms": 1e3 * t_env,
+                    "planner_budget": "Ntree 30, Nsims 10, horizon 4, xdt 5, Ncycles 5, 3 robots per world (experiments/src/dmcts.py:31-36,74-78)",
+                    "planner_tree_grows_per_s": N * grows / t_plan, "planner_rollouts_per_s": N * grows * 10 / t_plan,
+                    "planner_workspace_GB": planner.workspace.numel() / 1e9,
+                    "visibility_queries_per_s": Q / t_vis, "rollouts_per_s_horizon4": Qr * nsims / t_ro,
                     "rollout_visibility_queries_per_s": Qr * nsims * H / t_ro,
                     "l2_hit_rate": None, "l2_hit_rate_source": "profiles/ (rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum pass), not measured in this run"}
         extra["cfg5"] = cfg5_extra
@@ -323,6 +368,7 @@ def main():
         ev1.record()
         barrier()
         el = time.perf_counter() - t0
+        stats_state["block"] += 1
         if world_size > 1:
             t = torch.tensor([el], dtype=torch.float64, device=device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -331,36 +377,62 @@ def main():
 
     run(args.warmup)
     barrier()
+    if world_size > 1:
+        # duration of the statistics collective (pack kernel + all-gather, bracketed by synchronize), median of 5, on its own
+        tc = []
+        for _ in range(5):
+            barrier()
+            t0 = time.perf_counter()
+            gather_stats(env, force=True)
+            barrier()
+            tc.append(time.perf_counter() - t0)
+        stats_state["collective_ms"] = 1e3 * sorted(tc)[2]
+        stats_state["every"] = 1 << 30  # not during the probe block below
     blocks = [timed_block()]
+    if world_size > 1:
+        # one block in `every` carries the collective: at most 1 % of the timed time (same value on every rank)
+        ev = max(1, int(-(-stats_state["collective_ms"] * 1e-3 // (0.01 * max(blocks[0][0], 1e-6)))))
+        r = torch.tensor([ev], dtype=torch.int64, device=device)
+        dist.all_reduce(r, op=dist.ReduceOp.MAX)
+        stats_state["every"] = int(r.item())
     if args.repeats > 0:
         repeats = args.repeats
-    else:  # at least 5 blocks; short blocks are repeated until about 2 s are on the clock (same count on every rank)
-        repeats = int(min(400, max(5, 2.0 / max(blocks[0][0], 1e-6))))
+    else:  # at least 5 blocks; short blocks are repeated until 2 s are on the clock whatever --steps is (same count on every rank)
+        repeats = int(min(50000, max(5, 2.0 / max(blocks[0][0], 1e-6))))
         if world_size > 1:
             r = torch.tensor([repeats], dtype=torch.int64, device=device)
             dist.broadcast(r, 0)
             repeats = int(r.item())
     while len(blocks) < repeats:
         blocks.append(timed_block())
+    if world_size > 1:
+        gather_stats(env, force=True)  # the final counters
+        barrier()
     walls = sorted(b[0] for b in blocks)
     elapsed = walls[len(walls) // 2]  # median block
     dev_sorted = sorted(b[1] for b in blocks)
     dev_ms = dev_sorted[len(dev_sorted) // 2]
     launches = blocks[0][2]
 
-    st = stats_mod.summarize(gathered if gathered is not None else stats_mod.pack_episode_stats(env.episode_stats()))
+    st = stats_mod.summarize(gathered if gathered is not None else env.packed_episode_stats())
     if rank == 0:
         total_worlds = N * world_size if scaling == "weak" else total
         value = total_worlds * args.steps / elapsed
         steps_per_launch = args.steps / launches
-        launch_ms = dev_ms / launches
+        launch_ms_dev = dev_ms / launches            # HIP events around the block, median
+        launch_ms = 1e3 * elapsed / launches         # the wall clock `value` is computed from: ONE clock for the whole line
         achieved = balg * N * M * steps_per_launch / (launch_ms * 1e-3) / 1e9
+        achieved_dev = balg * N * M * steps_per_launch / (launch_ms_dev * 1e-3) / 1e9
         # HBM bytes per launch from the PMC counters are NOT collected in this run (they need rocprofv3 --pmc passes);
         # the figure below replays profiles/ (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes) for the
         # headline shape only and is labelled as such; null for any other shape.
         traffic = None
-        traffic_per_agent_step = 417.7 + 395.0 / steps_per_launch
-        if (N, M, policy, args.per_step_launch) == (4096, 10, "rvo", False):
+        replay = None  # counters of the headline shape, collected by the rocprofv3 --pmc passes of tools/final_profile_r3.sh
+        rp = os.path.join(ROOT, "profiles", "r3", "headline_pmc.json")
+        if (N, M, policy, args.per_step_launch) == (4096, 10, "rvo", False) and os.path.exists(rp):
+            replay = json.load(open(rp))
+        traffic_per_agent_step = (replay["hbm_bytes_per_agent_step"] + replay.get("hbm_bytes_per_agent_per_launch", 0.0) / steps_per_launch) if replay else None
+        if replay:
             traffic = traffic_per_agent_step * N * M * steps_per_launch / (launch_ms * 1e-3) / 1e9  # GB/s, comparable to `achieved`
         # measured device-to-device copy ceiling next to the vendor HBM figure: read + write of 1 GiB
         src = torch.empty(1 << 30, dtype=torch.uint8, device=device)
@@ -385,15 +457,26 @@ def main():
                        "parallelism": "worlds sharded x%d, no data-path collective" % world_size},
             "repeats": len(blocks), "timing": "median of %d timed blocks of %d steps" % (len(blocks), args.steps),
             "ms_per_step_min": 1e3 * walls[0] / args.steps, "ms_per_step_max": 1e3 * walls[-1] / args.steps,
+            "timed_region_s": sum(walls),
             "rccl_ranks": world_size if (world_size > 1 and backend == "nccl") else 0,
+            "stats_collective": None if world_size == 1 else {
+                "ms": stats_state["collective_ms"], "every_blocks": stats_state["every"],
+                "share_of_timed_time": stats_state["collective_ms"] * 1e-3 / (stats_state["every"] * max(elapsed, 1e-9)),
+                "what": "cagym_pack_episode_stats (one kernel) + all-gather of 24-byte records on a side stream, issued in one of every_blocks timed blocks; joined only by the block's closing synchronize"},
             "collective_backend": backend if world_size > 1 else None,
             "agent_steps_per_s": value * M,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": None if traffic is None else
-                         "replayed from profiles/r2 PMC passes of this shape (FETCH_SIZE x2 + WRITE_SIZE per agent-step), not measured in this run",
+                         "replayed from profiles/r3/headline_pmc.json (rocprofv3 --pmc passes of this shape: FETCH_SIZE x2 + WRITE_SIZE per agent-step), not measured in this run",
+                         # what actually bounds the kernel (the HBM fraction above is the metric BASELINE.json asks for): VALU issue
+                         "valu_busy": replay["valu_busy"] if replay else None,
+                         "valu_insts_per_agent_step": replay["valu_insts_per_agent_step"] if replay else None,
+                         "valu_source": None if not replay else "replayed from profiles/r3/headline_pmc.json (SQ_ACTIVE_INST_VALU, SQ_INSTS_VALU, GRBM_GUI_ACTIVE of the %s-step launches), not measured in this run" % replay.get("steps_per_launch", "512"),
                          "kernel": kernel_name,
-                         "launch_ms": launch_ms, "launch_ms_min": dev_sorted[0] / launches, "launch_ms_max": dev_sorted[-1] / launches,
+                         "clock": "wall-clock median block (the clock of `value` and `ms_per_step`: frac = alg_bytes_per_agent_step x agents x worlds / ms_per_step / peak)",
+                         "launch_ms": launch_ms, "launch_ms_min": 1e3 * walls[0] / launches, "launch_ms_max": 1e3 * walls[-1] / launches,
+                         "launch_ms_hip_events": launch_ms_dev, "achieved_hip_events": achieved_dev, "frac_hip_events": achieved_dev / HBM_PEAK_GBS,
                          "alg_bytes_per_agent_step": balg,
                          "measured_d2d_copy_GBs": copy_gbs,
                          "alg_bytes_per_launch": balg * N * M * steps_per_launch,

@@ -80,6 +80,7 @@ def load():
     L.cagym_rollout.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(CagymOutputs), C.c_void_p]
     L.cagym_get_state.argtypes = [C.c_void_p, C.POINTER(CagymStatePtrs)]
     L.cagym_laserscan.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.cagym_pack_episode_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.cagym_occupancy_grid.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.cagym_generate_scenarios.argtypes = [C.c_void_p, C.POINTER(CagymGenParams), C.POINTER(C.c_int32), C.c_void_p]
     L.cagym_get_scenarios.argtypes = [C.c_void_p, C.POINTER(CagymScenarioPtrs)]

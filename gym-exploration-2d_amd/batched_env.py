@@ -230,6 +230,15 @@ class BatchedCollisionAvoidanceEnv(object):
         s = self.state()
         return {k: s[k] for k in ("stat_return", "stat_episodes", "stat_steps", "stat_outcomes")}
 
+    def packed_episode_stats(self, out=None):
+        """[N, 6] int32 records (stats.py layout) written by ONE kernel on the current stream (cagym_pack_episode_stats)."""
+        if out is None:
+            out = torch.empty((self.N, 6), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = self.L.cagym_pack_episode_stats(self.h, out.data_ptr(), self._stream())
+        _lib.check(self.L, self.h, rc, "cagym_pack_episode_stats")
+        return out
+
     # ---- parity-test interface (f/u/i accessors used by tests/golden_util.replay) ----------------------------
     def f(self, name):
         torch.cuda.synchronize(self.device)

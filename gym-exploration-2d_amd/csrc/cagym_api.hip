@@ -592,6 +592,26 @@ int cagym_get_state(void* env, cagym_state_ptrs* out) {
     return CAGYM_OK;
 }
 
+// one 24-byte record per world (cagym.h: cagym_pack_episode_stats)
+__global__ void __launch_bounds__(256) k_pack_stats(CagymDev D, int32_t* __restrict__ rec) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= D.N) return;
+    int2* r = reinterpret_cast<int2*>(rec + (size_t)w * 6);  // 24-byte records: 8-byte aligned
+    r[0] = make_int2(__float_as_int(D.stat_return[w]), D.stat_episodes[w]);
+    r[1] = make_int2(D.stat_steps[w], D.stat_outcomes[3 * w]);
+    r[2] = make_int2(D.stat_outcomes[3 * w + 1], D.stat_outcomes[3 * w + 2]);
+}
+
+int cagym_pack_episode_stats(void* env, int32_t* records, void* stream) {
+    Env* e = reinterpret_cast<Env*>(env);
+    if (!e) return fail(nullptr, CAGYM_E_INVALID, "null env");
+    if (!records) return fail(e, CAGYM_E_INVALID, "null records buffer");
+    DEVGUARD(e);
+    hipLaunchKernelGGL(k_pack_stats, dim3((unsigned)((e->cfg.n_worlds + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), e->D, records);
+    HIPCHK(e, hipGetLastError());
+    return CAGYM_OK;
+}
+
 static void launch_ga3c_state(Env* e, int max_observed, const int32_t* agent_idx, long long rows, const int32_t* B_dev, float* state,
                               hipStream_t st) {
     if (e->cfg.max_agents <= 16)
@@ -707,6 +727,7 @@ int cagym_ig_init(void* env, void* stream) {
         int rc;
         if ((rc = dalloc(e, &e->G.d2, S * CAGYM_MAPD * CAGYM_MAPD)) != CAGYM_OK) return rc;
         if ((rc = dalloc(e, &e->G.belief, N * IG_BEL * IG_BEL)) != CAGYM_OK) return rc;
+        if ((rc = dalloc(e, &e->G.mi, N * IG_BEL * IG_BEL)) != CAGYM_OK) return rc;
         if ((rc = dalloc(e, &e->ig_any, S)) != CAGYM_OK) return rc;
     }
     e->G.N = (int)N; e->G.S = (int)S; e->G.map_bits = e->D.map_bits; e->G.sc_nobst = e->D.sc_nobst; e->G.episode = e->D.episode;
@@ -822,13 +843,15 @@ int cagym_ig_rollouts(void* env, const double* pose0, const uint64_t* observed0,
 
 namespace {
 inline int dm_node_cap(const cagym_dmcts_params& p) { return 1 + 9 * (p.Ntree * p.Ncycles + 1); }
+inline int dm_mask_cap(const cagym_dmcts_params& p) { return 1 + p.Ntree * p.Ncycles; }  // the root + one newly selected node per grow
 inline size_t dm_align(size_t x) { return (x + 255) & ~(size_t)255; }
 }  // namespace
 
 size_t cagym_dmcts_workspace_bytes(int n_worlds, const cagym_dmcts_params* p) {
     if (!p || n_worlds < 1 || p->n_robots < 1 || p->Ntree < 1 || p->Ncycles < 1) return 0;
     const size_t trees = (size_t)n_worlds * p->n_robots;
-    return dm_align(trees * sizeof(DmPublished)) + dm_align(trees * sizeof(int32_t)) + trees * (size_t)dm_node_cap(*p) * sizeof(DmNode);
+    return dm_align(trees * sizeof(DmPublished)) + dm_align(trees * 2 * sizeof(int32_t)) + dm_align(trees * (size_t)dm_node_cap(*p) * sizeof(DmNode)) +
+           trees * (size_t)dm_mask_cap(*p) * sizeof(DmMasks);
 }
 
 int cagym_dmcts_plan(void* env, const cagym_dmcts_params* params, const double* poses, void* workspace,
@@ -850,13 +873,14 @@ int cagym_dmcts_plan(void* env, const cagym_dmcts_params* params, const double* 
     unsigned char* base = reinterpret_cast<unsigned char*>(workspace);
     DmPublished* pub = reinterpret_cast<DmPublished*>(base);
     int32_t* nn = reinterpret_cast<int32_t*>(base + dm_align(trees * sizeof(DmPublished)));
-    DmNode* nodes = reinterpret_cast<DmNode*>(base + dm_align(trees * sizeof(DmPublished)) + dm_align(trees * sizeof(int32_t)));
+    DmNode* nodes = reinterpret_cast<DmNode*>(base + dm_align(trees * sizeof(DmPublished)) + dm_align(trees * 2 * sizeof(int32_t)));
+    DmMasks* masks = reinterpret_cast<DmMasks*>(reinterpret_cast<unsigned char*>(nodes) + dm_align(trees * (size_t)dm_node_cap(p) * sizeof(DmNode)));
     if (p.reset_comms) HIPCHK(e, hipMemsetAsync(pub, 0, trees * sizeof(DmPublished), st));
     DmParams P;
     P.R = p.n_robots; P.Ntree = p.Ntree; P.Nsims = p.Nsims; P.horizon = p.horizon; P.Ncycles = p.Ncycles; P.comm_n = p.comm_n;
-    P.node_cap = dm_node_cap(p); P.xdt = p.xdt; P.call_base = p.call_base;
+    P.node_cap = dm_node_cap(p); P.mask_cap = dm_mask_cap(p); P.xdt = p.xdt; P.call_base = p.call_base;
     P.c_p = p.c_p; P.gamma = p.gamma; P.radius = p.radius; P.dt = p.dt; P.fov = p.fov_rad; P.range = p.range; P.seed = p.seed;
-    hipLaunchKernelGGL(k_dmcts_plan, dim3((unsigned)N), dim3(DM_THREADS), 0, st, e->G, P, poses, nodes, nn, pub, actions, paths, stats);
+    hipLaunchKernelGGL(k_dmcts_plan, dim3((unsigned)N), dim3(DM_THREADS), 0, st, e->G, P, poses, nodes, masks, nn, pub, actions, paths, stats);
     HIPCHK(e, hipGetLastError());
     return CAGYM_OK;
 }

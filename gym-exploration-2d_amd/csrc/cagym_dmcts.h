@@ -7,9 +7,17 @@
 // (DecMCTSPlanner, host tree over the same device primitives): generator keys, summation orders and tie rules are
 // the same, and the two make identical decisions (tests/test_dmcts.py).
 //
-// Tree bookkeeping is a few scalar operations per grow and runs on lane 0; what costs time -- visibility sets of
-// new children, the Nsims x (horizon - stage) roll-out steps, the MI rewards, the top-n scan -- is spread over the
-// workgroup with the functions of cagym_ig.h (so the numbers are those of cagym_ig_rollouts bit for bit).
+// Tree bookkeeping is a few scalar operations per grow and runs on lane 0; what costs time -- the visibility set of a newly
+// selected node, the Nsims x (horizon - stage) roll-out steps, the MI rewards, the top-n scan -- is spread over the workgroup
+// with the functions of cagym_ig.h (so the numbers are those of cagym_ig_rollouts bit for bit).
+//
+// Round 3 (profiles/r3/cfg5_*): (1) the Nsims roll-outs of a grow are independent: each of the workgroup's 4 waves runs
+// whole roll-outs on its own (visibility masks private to the wave, no workgroup barrier inside a roll-out; the MI sum keeps
+// the summation order of the 128-thread block reduction, so every reward is the same double); (2) a node's "observed" mask
+// (parent's mask | cells visible from its pose) is only ever read once the node has been SELECTED, so it is built then and
+// not for each of the up to nine children at expansion - a quarter of the visibility queries of a grow - and the two 480-byte
+// masks live in a pool with one entry per selected node: 80-byte nodes, 1.6 GB of workspace for 2048 worlds x 3 robots at
+// the experiment's budget instead of 8.7 GB.
 #pragma once
 #include "cagym_ig.h"
 
@@ -17,18 +25,22 @@
 #define DM_MAXCOMM 8   // communicated plans per robot
 #define DM_MAXR 8      // IG robots per world
 #define DM_MAXSIMS 32
-#define DM_THREADS 128
+#define DM_THREADS 256
+#define DM_WAVES (DM_THREADS / 64)
+#define DM_VT 128      // virtual threads of the MI block reduction (ig_reward_block's order in cagym_ig_rollouts)
 #define DM_NOACT 255   // no action stored
 #define DM_INFEAS 254  // infeasible random draw: the roll-out appended (0, 0) (ig_mcts.py:226-231)
 
-struct DmNode {
+struct DmNode {  // 80 bytes
     double mu, Nv, best;
     double pose[3];
     int32_t parent, child0;
+    int32_t mask;    // entry of the tree's mask pool, -1 until the node is selected for the first time
     uint8_t nchild, stage, has_roll, seq_len;
     uint8_t acts[DM_MAXH];  // own action sequence from the root (stage entries)
     uint8_t seq[DM_MAXH];   // best roll-out through this node: full action sequence from the root (seq_len entries)
-    uint32_t pad;
+};
+struct DmMasks {  // 960 bytes, one per selected node
     unsigned long long observed[IG_BEL];  // cells observed on the way to this node
     unsigned long long best_obs[IG_BEL];  // cells observed along the best roll-out through this node
 };
@@ -42,7 +54,7 @@ struct DmPublished {
 };
 
 struct DmParams {
-    int R, Ntree, Nsims, horizon, Ncycles, comm_n, node_cap, xdt;
+    int R, Ntree, Nsims, horizon, Ncycles, comm_n, node_cap, mask_cap, xdt;
     unsigned int call_base;
     double c_p, gamma, radius, dt, fov, range;
     unsigned long long seed;
@@ -58,9 +70,9 @@ __device__ __forceinline__ void dm_prim(int k, double& v, double& w) {  // mcts_
     w = k % 3 == 0 ? -0.5 * kPi : (k % 3 == 1 ? 0.0 : 0.5 * kPi);
 }
 
-// Tree._expansion (DecMCTS.py:201-231): one child per feasible primitive, in primitive order.
-__device__ inline void dm_expand(const uint32_t* d2, DmNode* T, int* n_nodes, int s, const DmParams& P,
-                                 unsigned long long* vis, double* cpose, int* cfeas, int tid) {
+// Tree._expansion (DecMCTS.py:201-231): one child per feasible primitive, in primitive order.  The children get their pose;
+// their observed-cells mask is built when (if) they are selected (dm_materialise).
+__device__ inline void dm_expand(const uint32_t* d2, DmNode* T, int* n_nodes, int s, const DmParams& P, double* cpose, int* cfeas, int tid) {
     const int stage = T[s].stage;
     if (stage >= P.horizon || T[s].nchild != 0) return;  // uniform: every lane reads the same node
     if (tid < 9) {
@@ -71,28 +83,20 @@ __device__ inline void dm_expand(const uint32_t* d2, DmNode* T, int* n_nodes, in
         cpose[3 * tid] = x; cpose[3 * tid + 1] = y; cpose[3 * tid + 2] = th;
     }
     __syncthreads();
-    const int first = *n_nodes;
-    int cnt = 0;
-    for (int k = 0; k < 9; k++) {
-        if (!cfeas[k] || first + cnt >= P.node_cap) continue;  // a full pool stops growing (sized so it never is)
-        const int c = first + cnt;
-        ig_visible_block(d2, cpose[3 * k], cpose[3 * k + 1], cpose[3 * k + 2], P.fov, P.range, vis, tid, DM_THREADS);
-        for (int j = tid; j < IG_BEL; j += DM_THREADS) {
-            T[c].observed[j] = T[s].observed[j] | vis[j];
-            T[c].best_obs[j] = 0ull;
-        }
-        if (tid == 0) {
-            T[c].mu = 0.0; T[c].Nv = 0.0; T[c].best = 0.0;
-            T[c].pose[0] = cpose[3 * k]; T[c].pose[1] = cpose[3 * k + 1]; T[c].pose[2] = cpose[3 * k + 2];
-            T[c].parent = s; T[c].child0 = -1;
-            T[c].nchild = 0; T[c].stage = (uint8_t)(stage + 1); T[c].has_roll = 0; T[c].seq_len = 0;
-            for (int a = 0; a < DM_MAXH; a++) { T[c].acts[a] = a < stage ? T[s].acts[a] : DM_NOACT; T[c].seq[a] = DM_NOACT; }
-            T[c].acts[stage] = (uint8_t)k;
-        }
-        cnt++;
-        __syncthreads();
-    }
     if (tid == 0) {
+        const int first = *n_nodes;
+        int cnt = 0;
+        for (int k = 0; k < 9; k++) {
+            if (!cfeas[k] || first + cnt >= P.node_cap) continue;  // a full pool stops growing (sized so it never is)
+            DmNode& c = T[first + cnt];
+            c.mu = 0.0; c.Nv = 0.0; c.best = 0.0;
+            c.pose[0] = cpose[3 * k]; c.pose[1] = cpose[3 * k + 1]; c.pose[2] = cpose[3 * k + 2];
+            c.parent = s; c.child0 = -1; c.mask = -1;
+            c.nchild = 0; c.stage = (uint8_t)(stage + 1); c.has_roll = 0; c.seq_len = 0;
+            for (int a = 0; a < DM_MAXH; a++) { c.acts[a] = a < stage ? T[s].acts[a] : DM_NOACT; c.seq[a] = DM_NOACT; }
+            c.acts[stage] = (uint8_t)k;
+            cnt++;
+        }
         T[s].child0 = cnt ? first : -1;
         T[s].nchild = (uint8_t)cnt;
         *n_nodes = first + cnt;
@@ -100,48 +104,200 @@ __device__ inline void dm_expand(const uint32_t* d2, DmNode* T, int* n_nodes, in
     __syncthreads();
 }
 
-__global__ void __launch_bounds__(DM_THREADS) k_dmcts_plan(IgDev G, DmParams P, const double* poses, DmNode* nodes,
+// The masks of a node that is selected for the first time: observed = parent's observed | cells visible from its pose
+// (mcts_sim_state_storer, ig_mcts.py:210-232).  The parent was selected before (it has children), the root at start-up.
+__device__ inline void dm_materialise(const uint32_t* d2, DmNode* T, DmMasks* MK, int* n_masks, int s, const DmParams& P,
+                                      unsigned long long* vis, int tid) {
+    if (T[s].mask >= 0) return;  // uniform
+    const int m = *n_masks;      // (read by every lane before lane 0 bumps it below, behind the barriers of the visibility block)
+    ig_visible_block(d2, T[s].pose[0], T[s].pose[1], T[s].pose[2], P.fov, P.range, vis, tid, DM_THREADS);
+    const DmMasks& pm = MK[T[T[s].parent].mask];
+    for (int j = tid; j < IG_BEL; j += DM_THREADS) {
+        MK[m].observed[j] = pm.observed[j] | vis[j];
+        MK[m].best_obs[j] = 0ull;
+    }
+    __syncthreads();
+    if (tid == 0) { T[s].mask = m; *n_masks = m + 1; }
+    __syncthreads();
+}
+
+// ---- one roll-out on ONE wave ---------------------------------------------------------------------------------------------
+// targetMap.getVisibleCells on the 64 lanes of a wave into the wave's own LDS mask (no workgroup barrier: a wave's LDS
+// operations complete in program order; the fences keep the compiler from reordering them).  Same set as ig_visible_block.
+__device__ __forceinline__ void dm_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// Two passes: (1) every lane classifies its share of the window's cells by the cone test and the cells inside are appended
+// to the wave's list (ballot + prefix count); (2) the sphere traces - whose length varies from cell to cell and is what costs -
+// run on dense lanes, one listed cell per lane and round (before: a lane traced the 0..3 cone cells that happened to be among
+// its own window cells, the wave waiting for the unluckiest lane).
+__device__ inline void dm_visible_wave(const uint32_t* d2, double px, double py, double phi, double fov, double range,
+                                       unsigned long long* vis, uint16_t* list, int lane) {
+    if (lane < IG_BEL) vis[lane] = 0ull;
+    dm_wave_sync();
+    double s, c;
+    ig_sincos(phi, &s, &c);
+    double sl, cl, sr, cr;
+    ig_sincos(phi + fov, &sl, &cl);
+    ig_sincos(phi - fov, &sr, &cr);
+    int cx[4] = {ig_bel_cell(px), ig_bel_cell(ig_clamp(px + range * c)), ig_bel_cell(ig_clamp(px + range * cl)),
+                 ig_bel_cell(ig_clamp(px + range * cr))};
+    int cy[4] = {ig_bel_cell(py), ig_bel_cell(ig_clamp(py + range * s)), ig_bel_cell(ig_clamp(py + range * sl)),
+                 ig_bel_cell(ig_clamp(py + range * sr))};
+    int xs = min(min(cx[0], cx[1]), min(cx[2], cx[3])), xe = max(max(cx[0], cx[1]), max(cx[2], cx[3]));
+    int ys = min(min(cy[0], cy[1]), min(cy[2], cy[3])), ye = max(max(cy[0], cy[1]), max(cy[2], cy[3]));
+    xs = max(xs, 0);
+    ys = max(ys, 0);
+    xe = min(xe, IG_BEL);
+    ye = min(ye, IG_BEL);
+    const int w = xe - xs, h = ye - ys;
+    const int total = (w > 0 && h > 0) ? w * h : 0;
+    const double hf = fov / 2;
+    const bool fast = hf > 1e-6 && hf < 1.5;  // the cone test by products where the margin allows (see ig_visible_block)
+    const double t_in = fast ? tan(hf - 1e-9) : 0.0, t_out = fast ? tan(hf + 1e-9) : 0.0;
+    const double r2_in = range * range * (1.0 - 1e-12), r2_out = range * range * (1.0 + 1e-12);
+    constexpr int CAP = IG_BEL * IG_BEL / 4;  // list entries of a wave; a larger window is worked off in slices of CAP cells
+    for (int base = 0; base < total; base += CAP) {
+        const int lim = total - base < CAP ? total : base + CAP;
+        int n = 0;  // cells in the cone so far (wave-uniform)
+        for (int q0 = base; q0 < lim; q0 += 64) {
+            const int q = q0 + lane;
+            bool inside = false;
+            int i = 0, j = 0;
+            if (q < lim) {
+                i = xs + q / h;
+                j = ys + q % h;
+                double cxp = (i)*IG_BEL_CELL - IG_HALF + IG_BEL_CELL / 2, cyp = (j)*IG_BEL_CELL - IG_HALF + IG_BEL_CELL / 2;
+                double r0, r1;
+                mat2vec(c, s, cxp - px, cyp - py, r0, r1);
+                const double rn2 = r0 * r0 + r1 * r1, a1 = fabs(r1);
+                if (fast && (rn2 > r2_out || !(r0 > 0.0) || a1 > r0 * t_out)) inside = false;
+                else if (fast && rn2 < r2_in && a1 < r0 * t_in) inside = true;
+                else {
+                    double dphi = atan2(r1, r0);
+                    double rn = sqrt(rn2);
+                    inside = rn < range && fabs(dphi) < fov / 2;
+                }
+            }
+            const unsigned long long m = __ballot(inside);
+            if (inside) list[n + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)((i << 8) | j);  // i, j < 60
+            n += __popcll(m);
+        }
+        dm_wave_sync();
+        for (int e0 = 0; e0 < n; e0 += 64) {
+            const int e = e0 + lane;
+            if (e < n) {
+                const int i = list[e] >> 8, j = list[e] & 255;
+                double cxp = (i)*IG_BEL_CELL - IG_HALF + IG_BEL_CELL / 2, cyp = (j)*IG_BEL_CELL - IG_HALF + IG_BEL_CELL / 2;
+                if (ig_check_visibility(d2, px, py, cxp, cyp)) atomicOr(&vis[j], 1ull << i);
+            }
+        }
+        dm_wave_sync();
+    }
+}
+
+// ig_mcts.get_next_pose (ig_mcts.py:154-183) on one wave: the xdt sub-steps' headings are a running sum (cheap, sequential),
+// their sines / cosines and the distance-field tests are independent: lane k < xdt evaluates sub-step k, the positions are then
+// accumulated in order from the lanes' velocities (same additions in the same order as ig_next_pose: same doubles).  Uniform
+// result on every lane.  xdt <= 64 (larger: the sequential version).
+__device__ inline bool dm_next_pose_wave(const uint32_t* d2, double& x, double& y, double& th, double v, double w, int xdt,
+                                         double dt, double radius, int lane) {
+    if (xdt > 64) return ig_next_pose(d2, x, y, th, v, w, xdt, dt, radius);
+    double nt = th;  // heading BEFORE sub-step `lane`: th + w dt + w dt ... (lane additions, in order)
+    for (int k = 0; k < xdt; k++)
+        if (k < lane) nt = nt + w * dt;
+    double sn, cs;
+    ig_sincos(nt, &sn, &cs);
+    const double vx = fma(cs, v, -sn * 0.0) * dt, vy = fma(sn, v, cs * 0.0) * dt;  // this sub-step's displacement
+    double nx = x, ny = y, mx = 0.0, my = 0.0;  // (mx, my): the position AFTER sub-step `lane`
+    for (int k = 0; k < xdt; k++) {
+        nx = nx + __shfl(vx, k, 64);
+        ny = ny + __shfl(vy, k, 64);
+        if (k == lane) { mx = nx; my = ny; }
+    }
+    bool bad = false;
+    if (lane < xdt && v != 0.0) {
+        const bool in_map = (IG_HALF > mx) && (IG_HALF > my) && (mx > -IG_HALF) && (my > -IG_HALF);
+        bad = !in_map || !(edf_at(d2, mx, my) > radius + 0.1);
+    }
+    if (__ballot(bad) != 0ull) return false;
+    double tt = th;
+    for (int k = 0; k < xdt; k++) tt = tt + w * dt;
+    x = nx;
+    y = ny;
+    th = tt;
+    return true;
+}
+// MI sum over the cells of `mask` on one wave in the summation order of ig_reward_block with DM_VT = 128 threads: lane l
+// carries the partial sums of the virtual threads l and l + 64 (each over q = vt, vt + 128, ... ascending), adds them as
+// the reduction's first level does (red[l] += red[l + 64]) and the remaining levels run through lane shuffles.
+__device__ inline double dm_reward_wave(const double* belief, const unsigned long long* mask, int lane) {
+    double a0 = 0.0, a1 = 0.0;
+    for (int q = lane; q < IG_BEL * IG_BEL; q += DM_VT) {
+        const int j = q / IG_BEL, i = q - j * IG_BEL;
+        if ((mask[j] >> i) & 1ull) a0 += belief[q];
+    }
+    for (int q = lane + 64; q < IG_BEL * IG_BEL; q += DM_VT) {
+        const int j = q / IG_BEL, i = q - j * IG_BEL;
+        if ((mask[j] >> i) & 1ull) a1 += belief[q];
+    }
+    double r = a0 + a1;
+    for (int s = 32; s > 0; s >>= 1) r = r + __shfl_down(r, s, 64);
+    return __shfl(r, 0, 64);
+}
+
+__global__ void __launch_bounds__(DM_THREADS) k_dmcts_plan(IgDev G, DmParams P, const double* poses, DmNode* nodes, DmMasks* masks,
                                                          int32_t* n_nodes_all, DmPublished* pub_all, double* out_actions,
                                                          uint8_t* out_paths, double* out_stats) {
-    __shared__ unsigned long long vis[IG_BEL], obs[IG_BEL], excl[IG_BEL], bobs[IG_BEL];
+    __shared__ unsigned long long vis[IG_BEL], excl[IG_BEL], bobs[IG_BEL];
+    __shared__ unsigned long long wvis[DM_WAVES][IG_BEL], wobs[DM_WAVES][IG_BEL], wbobs[DM_WAVES][IG_BEL];  // a wave's own masks
+    __shared__ uint16_t wlist[DM_WAVES][IG_BEL * IG_BEL / 4];  // cone cells of the wave's current visibility query (a 60-degree cone of 5 m holds < 100)
+    __shared__ uint8_t wtail[DM_WAVES][DM_MAXH], wbtail[DM_WAVES][DM_MAXH];
+    __shared__ double wbest[DM_WAVES];
+    __shared__ int wbest_sim[DM_WAVES];
     __shared__ double red[DM_THREADS];
     __shared__ int redi[DM_THREADS];
     __shared__ double cpose[27];
     __shared__ int cfeas[9];
     __shared__ double rew[DM_MAXSIMS];
-    __shared__ uint8_t tail[DM_MAXH], btail[DM_MAXH];
+    __shared__ uint8_t btail[DM_MAXH];
     __shared__ int sh_sel, sh_pick, sh_n;
     __shared__ int picks[DM_MAXCOMM];
     __shared__ int dist_idx[DM_MAXR][DM_MAXCOMM];
     __shared__ double dist_q[DM_MAXR][DM_MAXCOMM];
     __shared__ int dist_n[DM_MAXR];
     const int w = blockIdx.x, tid = threadIdx.x, R = P.R, H = P.horizon;
+    const int wave = tid >> 6, lane = tid & 63;
     const uint32_t* d2 = G.d2 + (size_t)ig_scenario(G, w) * CAGYM_MAPD * CAGYM_MAPD;
-    const double* belief = G.belief + (size_t)w * IG_BEL * IG_BEL;
+    const double* belief = G.mi + (size_t)w * IG_BEL * IG_BEL;  // the MI cache of the world's belief (IgDev::mi)
     DmPublished* pub = pub_all + (size_t)w * R;
 
     // ---- Tree.__init__ (DecMCTS.py:92-138): root + expansion of the root; my_act_dist = the root state alone -----
     for (int r = 0; r < R; r++) {
         DmNode* T = nodes + ((size_t)w * R + r) * P.node_cap;
-        int* nn = n_nodes_all + (size_t)w * R + r;
-        for (int j = tid; j < IG_BEL; j += DM_THREADS) { T[0].observed[j] = 0ull; T[0].best_obs[j] = 0ull; }
+        DmMasks* MK = masks + ((size_t)w * R + r) * P.mask_cap;
+        int* nn = n_nodes_all + ((size_t)w * R + r) * 2;  // [0] nodes, [1] mask-pool entries
+        for (int j = tid; j < IG_BEL; j += DM_THREADS) { MK[0].observed[j] = 0ull; MK[0].best_obs[j] = 0ull; }
         if (tid == 0) {
             T[0].mu = 0.0; T[0].Nv = 0.0; T[0].best = 0.0;
             T[0].pose[0] = poses[((size_t)w * R + r) * 3]; T[0].pose[1] = poses[((size_t)w * R + r) * 3 + 1];
             T[0].pose[2] = poses[((size_t)w * R + r) * 3 + 2];
-            T[0].parent = -1; T[0].child0 = -1; T[0].nchild = 0; T[0].stage = 0; T[0].has_roll = 0; T[0].seq_len = 0;
+            T[0].parent = -1; T[0].child0 = -1; T[0].mask = 0; T[0].nchild = 0; T[0].stage = 0; T[0].has_roll = 0; T[0].seq_len = 0;
             for (int a = 0; a < DM_MAXH; a++) { T[0].acts[a] = DM_NOACT; T[0].seq[a] = DM_NOACT; }
-            *nn = 1;
+            nn[0] = 1; nn[1] = 1;
             dist_n[r] = 1; dist_idx[r][0] = 0; dist_q[r][0] = 1.0;
         }
         __syncthreads();
-        dm_expand(d2, T, nn, 0, P, vis, cpose, cfeas, tid);
+        dm_expand(d2, T, nn, 0, P, cpose, cfeas, tid);
     }
 
     for (int cycle = 0; cycle < P.Ncycles; cycle++) {
         for (int r = 0; r < R; r++) {
             DmNode* T = nodes + ((size_t)w * R + r) * P.node_cap;
-            int* nn = n_nodes_all + (size_t)w * R + r;
+            DmMasks* MK = masks + ((size_t)w * R + r) * P.mask_cap;
+            int* nn = n_nodes_all + ((size_t)w * R + r) * 2;
             for (int g = 0; g < P.Ntree; g++) {
                 const unsigned int call = P.call_base + (unsigned int)((cycle * R + r) * P.Ntree + g) + 1u;
                 // ---- _get_system_state (DecMCTS.py:182-194): one sampled plan per robot this one listens to -------
@@ -186,41 +342,57 @@ __global__ void __launch_bounds__(DM_THREADS) k_dmcts_plan(IgDev G, DmParams P, 
                 }
                 __syncthreads();
                 const int s = sh_sel;
-                dm_expand(d2, T, nn, s, P, vis, cpose, cfeas, tid);
-                // ---- simulation (DecMCTS.py:233-271, 296-327): Nsims random roll-outs from the selected node ----------
+                dm_materialise(d2, T, MK, nn + 1, s, P, vis, tid);
+                dm_expand(d2, T, nn, s, P, cpose, cfeas, tid);
+                // ---- simulation (DecMCTS.py:233-271, 296-327): Nsims random roll-outs from the selected node, one wave each ----
                 const int steps = H - T[s].stage;
                 const unsigned long long rseed = P.seed * 1000003ull + (unsigned long long)call;
-                double best = -INFINITY;
-                for (int sim = 0; sim < P.Nsims; sim++) {
-                    for (int j = tid; j < IG_BEL; j += DM_THREADS) obs[j] = T[s].observed[j];
-                    __syncthreads();
-                    double x = T[s].pose[0], y = T[s].pose[1], th = T[s].pose[2];
-                    for (int t = 0; t < steps; t++) {
-                        const uint32_t k = ig_rand_primitive(rseed, (uint32_t)w, (uint32_t)sim, (uint32_t)t);
-                        double v, wv;
-                        dm_prim((int)k, v, wv);
-                        const bool ok = ig_next_pose(d2, x, y, th, v, wv, P.xdt, P.dt, P.radius);  // uniform
-                        if (ok) {
-                            ig_visible_block(d2, x, y, th, P.fov, P.range, vis, tid, DM_THREADS);
-                            for (int j = tid; j < IG_BEL; j += DM_THREADS) obs[j] |= vis[j];
-                            __syncthreads();
+                const DmMasks& sm = MK[T[s].mask];
+                {
+                    double my_best = -INFINITY;
+                    int my_best_sim = 0x7fffffff;
+                    for (int sim = wave; sim < P.Nsims; sim += DM_WAVES) {
+                        unsigned long long* obs = wobs[wave];
+                        if (lane < IG_BEL) obs[lane] = sm.observed[lane];
+                        dm_wave_sync();
+                        double x = T[s].pose[0], y = T[s].pose[1], th = T[s].pose[2];
+                        for (int t = 0; t < steps; t++) {
+                            const uint32_t k = ig_rand_primitive(rseed, (uint32_t)w, (uint32_t)sim, (uint32_t)t);
+                            double v, wv;
+                            dm_prim((int)k, v, wv);
+                            const bool ok = dm_next_pose_wave(d2, x, y, th, v, wv, P.xdt, P.dt, P.radius, lane);  // uniform across the wave
+                            if (ok) {
+                                dm_visible_wave(d2, x, y, th, P.fov, P.range, wvis[wave], wlist[wave], lane);
+                                if (lane < IG_BEL) obs[lane] |= wvis[wave][lane];
+                                dm_wave_sync();
+                            }
+                            if (lane == 0) wtail[wave][t] = ok ? (uint8_t)k : (uint8_t)DM_INFEAS;
                         }
-                        if (tid == 0) tail[t] = ok ? (uint8_t)k : (uint8_t)DM_INFEAS;
+                        if (lane < IG_BEL) wvis[wave][lane] = obs[lane] & ~excl[lane];  // mcts_reward (ig_mcts.py:234-241)
+                        dm_wave_sync();
+                        const double rr = dm_reward_wave(belief, wvis[wave], lane);
+                        if (lane == 0) rew[sim] = rr;
+                        if (rr > my_best) {  // uniform across the wave; `if rew > best_reward` keeps the first maximum
+                            my_best = rr;
+                            my_best_sim = sim;
+                            if (lane < IG_BEL) wbobs[wave][lane] = obs[lane];
+                            if (lane < DM_MAXH) wbtail[wave][lane] = lane < steps ? wtail[wave][lane] : (uint8_t)DM_NOACT;
+                        }
+                        dm_wave_sync();
                     }
-                    for (int j = tid; j < IG_BEL; j += DM_THREADS) vis[j] = obs[j] & ~excl[j];  // mcts_reward (ig_mcts.py:234-241)
-                    __syncthreads();
-                    const double rr = ig_reward_block(belief, vis, red, tid, DM_THREADS);
-                    if (tid == 0) rew[sim] = rr;
-                    if (rr > best) {  // uniform; `if rew > best_reward` keeps the first maximum
-                        best = rr;
-                        for (int j = tid; j < IG_BEL; j += DM_THREADS) bobs[j] = obs[j];
-                        if (tid == 0)
-                            for (int t = 0; t < DM_MAXH; t++) btail[t] = t < steps ? tail[t] : (uint8_t)DM_NOACT;
-                    }
-                    __syncthreads();
+                    if (lane == 0) { wbest[wave] = my_best; wbest_sim[wave] = my_best_sim; }
                 }
+                __syncthreads();
+                // the first maximum in roll-out order: highest reward, lowest roll-out index among equals
+                int bw = 0;
+                for (int q = 1; q < DM_WAVES; q++)
+                    if (wbest[q] > wbest[bw] || (wbest[q] == wbest[bw] && wbest_sim[q] < wbest_sim[bw])) bw = q;
+                const double best = wbest[bw];
+                for (int j = tid; j < IG_BEL; j += DM_THREADS) bobs[j] = wbobs[bw][j];
+                if (tid < DM_MAXH) btail[tid] = wbtail[bw][tid];
+                __syncthreads();
                 // ---- back-propagation (DecMCTS.py:329-356) ----------------------------------------------------------------
-                for (int j = tid; j < IG_BEL; j += DM_THREADS) T[s].best_obs[j] = bobs[j];
+                for (int j = tid; j < IG_BEL; j += DM_THREADS) MK[T[s].mask].best_obs[j] = bobs[j];
                 if (tid == 0) {
                     double acc = 0.0;
                     for (int sim = 0; sim < P.Nsims; sim++) acc += rew[sim];
@@ -238,7 +410,7 @@ __global__ void __launch_bounds__(DM_THREADS) k_dmcts_plan(IgDev G, DmParams P, 
                     const bool better = best > T[a].best;
                     __syncthreads();
                     if (better)
-                        for (int j = tid; j < IG_BEL; j += DM_THREADS) T[a].best_obs[j] = bobs[j];
+                        for (int j = tid; j < IG_BEL; j += DM_THREADS) MK[T[a].mask].best_obs[j] = bobs[j];
                     if (tid == 0) {
                         T[a].mu = (P.gamma * T[a].mu * T[a].Nv + avg) / (T[a].Nv + 1);
                         T[a].Nv = P.gamma * T[a].Nv + 1;
@@ -253,7 +425,7 @@ __global__ void __launch_bounds__(DM_THREADS) k_dmcts_plan(IgDev G, DmParams P, 
                 }
                 // ---- _update_distribution (DecMCTS.py:162-180): top comm_n nodes by mu (first created first on ties),
                 //      those with a roll-out, q = mu^2 -------------------------------------------------------------------------
-                const int total = *nn;
+                const int total = nn[0];
                 for (int round = 0; round < P.comm_n; round++) {
                     double bm = -INFINITY;
                     int bi = 0x7fffffff;
@@ -301,7 +473,8 @@ __global__ void __launch_bounds__(DM_THREADS) k_dmcts_plan(IgDev G, DmParams P, 
             for (int q = 0; q < n; q++) {
                 const DmNode& src = T[dist_idx[r][q]];
                 // the root entry of a tree without roll-outs has no best roll-out: it stands for "stay", nothing observed
-                for (int j = tid; j < IG_BEL; j += DM_THREADS) pub[r].obs[q][j] = src.has_roll ? src.best_obs[j] : src.observed[j];
+                const DmMasks& srm = MK[src.mask];  // (distribution entries have a roll-out or are the root: their masks exist)
+                for (int j = tid; j < IG_BEL; j += DM_THREADS) pub[r].obs[q][j] = src.has_roll ? srm.best_obs[j] : srm.observed[j];
             }
             if (tid == 0) {
                 pub[r].n = n;
@@ -325,6 +498,6 @@ __global__ void __launch_bounds__(DM_THREADS) k_dmcts_plan(IgDev G, DmParams P, 
         const DmNode* T = nodes + ((size_t)w * R + r) * P.node_cap;
         out_stats[((size_t)w * R + r) * 3] = T[0].mu;
         out_stats[((size_t)w * R + r) * 3 + 1] = T[0].Nv;
-        out_stats[((size_t)w * R + r) * 3 + 2] = (double)n_nodes_all[(size_t)w * R + r];
+        out_stats[((size_t)w * R + r) * 3 + 2] = (double)n_nodes_all[((size_t)w * R + r) * 2];
     }
 }

@@ -22,12 +22,41 @@ struct IgDev {
     const uint32_t* map_bits;  // [S,300,10]
     const int32_t* sc_nobst;   // [S]
     const int32_t* episode;    // [N]
-    uint32_t* d2;              // [S,300,300]
+    uint32_t* d2;              // [S,300,300] squared cell distances (exact EDT).  Round 3 measured a pre-multiplied fp64 field
+                               //             (sqrt(d2) * 0.1 stored: one 8-byte load instead of load + conversion + fp64 sqrt + product,
+                               //             30 of a trace step's ~135 instructions): 5 % SLOWER (321 -> 304 M visibility queries/s) -
+                               //             the traces are bound by the gathers (twice the footprint), not by the arithmetic.
     double* belief;            // [N,60,60]
+    double* mi;                // [N,60,60] ig_cell_mi(belief): the mutual information of a cell depends on its belief alone, which only
+                               //           k_ig_fill_belief / k_ig_update change - the planner's thousands of reward sums per step read
+                               //           this cache instead of evaluating four logarithms per observed cell (same doubles, same order)
 };
 
 __device__ __forceinline__ int ig_scenario(const IgDev& G, int world) {
     return (int)(((long long)world + (long long)G.episode[world] * G.N) % G.S);
+}
+
+// sin and cos of a pose heading (|x| < 1e5 takes the short path: Cody-Waite reduction by pi/2 in two fma steps, the fdlibm
+// kernel polynomials on [-pi/4, pi/4]; < 1 ulp like the library's, a third of its instructions).  The roll-outs evaluate
+// eight of these per step (five motion sub-steps, three for the view cone): with the library's sincos they were half of
+// the planner's arithmetic (profiles/r3/cfg5_*).  Anything else (huge, NaN) goes to the library.
+__device__ __forceinline__ void ig_sincos(double x, double* sn, double* cs) {
+    if (!(fabs(x) < 1e5)) { sincos(x, sn, cs); return; }
+    const double kf = rint(x * 6.36619772367581382433e-01);  // 2 / pi
+    double r = fma(-kf, 1.57079632679489655800e+00, x);      // pi/2 rounded; the product is exact inside the fma
+    r = fma(-kf, 6.12323399573676603587e-17, r);             // pi/2 - the above
+    const double z = r * r;
+    // __kernel_sin / __kernel_cos (fdlibm, public domain constants)
+    const double ps = fma(z, fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08), 2.75573137070700676789e-06),
+                                              -1.98412698298579493134e-04), 8.33333333332248946124e-03), -1.66666666666666324348e-01);
+    const double sr = fma(z * r, ps, r);
+    const double pc = fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09), -2.75573143513906633035e-07),
+                                              2.48015872894767294178e-05), -1.38888888888741095749e-03), 4.16666666666666019037e-02);
+    const double cr = fma(z * z, pc, fma(-0.5, z, 1.0));
+    const int k = (int)kf & 3;
+    const double s0 = (k & 1) ? cr : sr, c0 = (k & 1) ? sr : cr;
+    *sn = (k & 2) ? -s0 : s0;
+    *cs = ((k + 1) & 2) ? -c0 : c0;
 }
 
 __device__ __forceinline__ void mat2vec(double c, double s, double vx, double vy, double& r0, double& r1) {
@@ -86,10 +115,10 @@ __device__ inline void ig_visible_block(const uint32_t* d2, double px, double py
     for (int j = tid; j < IG_BEL; j += nthreads) vis[j] = 0ull;
     __syncthreads();
     double s, c;
-    sincos(phi, &s, &c);
+    ig_sincos(phi, &s, &c);
     double sl, cl, sr, cr;
-    sincos(phi + fov, &sl, &cl);
-    sincos(phi - fov, &sr, &cr);
+    ig_sincos(phi + fov, &sl, &cl);
+    ig_sincos(phi - fov, &sr, &cr);
     int cx[4] = {ig_bel_cell(px), ig_bel_cell(ig_clamp(px + range * c)), ig_bel_cell(ig_clamp(px + range * cl)),
                  ig_bel_cell(ig_clamp(px + range * cr))};
     int cy[4] = {ig_bel_cell(py), ig_bel_cell(ig_clamp(py + range * s)), ig_bel_cell(ig_clamp(py + range * sl)),
@@ -102,14 +131,29 @@ __device__ inline void ig_visible_block(const uint32_t* d2, double px, double py
     ye = min(ye, IG_BEL);
     const int w = xe - xs, h = ye - ys;
     const int total = (w > 0 && h > 0) ? w * h : 0;
+    // The cone test `rn < range and |atan2(r1, r0)| < fov / 2` (targetMap.py:66-70) costs an fp64 atan2 and a square root per
+    // window cell, and two cells in three fail it.  A cell that is inside or outside by a margin far above the rounding of
+    // either side is decided by products alone (|r1| against r0 tan(fov/2 -+ 1e-9), rn^2 against range^2 (1 -+ 1e-12)); only
+    // a cell within those margins evaluates the reference's own expressions.  Same set, bit for bit.
+    const double hf = fov / 2;
+    const bool fast = hf > 1e-6 && hf < 1.5;
+    const double t_in = fast ? tan(hf - 1e-9) : 0.0, t_out = fast ? tan(hf + 1e-9) : 0.0;
+    const double r2_in = range * range * (1.0 - 1e-12), r2_out = range * range * (1.0 + 1e-12);
     for (int q = tid; q < total; q += nthreads) {
         int i = xs + q / h, j = ys + q % h;
         double cxp = (i)*IG_BEL_CELL - IG_HALF + IG_BEL_CELL / 2, cyp = (j)*IG_BEL_CELL - IG_HALF + IG_BEL_CELL / 2;
         double r0, r1;
         mat2vec(c, s, cxp - px, cyp - py, r0, r1);
-        double dphi = atan2(r1, r0);
-        double rn = sqrt(r0 * r0 + r1 * r1);
-        if (rn < range && fabs(dphi) < fov / 2) {
+        const double rn2 = r0 * r0 + r1 * r1, a1 = fabs(r1);
+        bool inside;
+        if (fast && (rn2 > r2_out || !(r0 > 0.0) || a1 > r0 * t_out)) inside = false;
+        else if (fast && rn2 < r2_in && a1 < r0 * t_in) inside = true;
+        else {
+            double dphi = atan2(r1, r0);
+            double rn = sqrt(rn2);
+            inside = rn < range && fabs(dphi) < fov / 2;
+        }
+        if (inside) {
             if (ig_check_visibility(d2, px, py, cxp, cyp)) atomicOr(&vis[j], 1ull << i);
         }
     }
@@ -127,12 +171,13 @@ __device__ __forceinline__ double ig_cell_mi(double r) {
 }
 
 // block-wide MI sum over the cells of `mask` (LDS), deterministic order.  red: LDS [nthreads] doubles.
-__device__ inline double ig_reward_block(const double* belief, const unsigned long long* mask, double* red, int tid,
+// mi: the world's cache of ig_cell_mi(belief) (IgDev::mi)
+__device__ inline double ig_reward_block(const double* mi, const unsigned long long* mask, double* red, int tid,
                                          int nthreads) {
     double acc = 0.0;
     for (int q = tid; q < IG_BEL * IG_BEL; q += nthreads) {
         int j = q / IG_BEL, i = q - j * IG_BEL;
-        if ((mask[j] >> i) & 1ull) acc += ig_cell_mi(belief[q]);
+        if ((mask[j] >> i) & 1ull) acc += mi[q];
     }
     red[tid] = acc;
     __syncthreads();
@@ -151,7 +196,7 @@ __device__ inline bool ig_next_pose(const uint32_t* d2, double& x, double& y, do
     double nx = x, ny = y, nt = th;
     for (int k = 0; k < xdt; k++) {
         double s, c;
-        sincos(nt, &s, &c);
+        ig_sincos(nt, &s, &c);
         double vx = fma(c, v, -s * 0.0), vy = fma(s, v, c * 0.0);
         nx = nx + vx * dt;
         ny = ny + vy * dt;
@@ -225,7 +270,9 @@ __global__ void __launch_bounds__(256) k_ig_fill_belief(IgDev G, const uint8_t* 
     const int w = blockIdx.x;
     if (mask && !mask[w]) return;
     double* b = G.belief + (size_t)w * IG_BEL * IG_BEL;
-    for (int q = threadIdx.x; q < IG_BEL * IG_BEL; q += blockDim.x) b[q] = 1.0;  // prior (targetMap.py:8)
+    double* m = G.mi + (size_t)w * IG_BEL * IG_BEL;
+    const double mi1 = ig_cell_mi(1.0);
+    for (int q = threadIdx.x; q < IG_BEL * IG_BEL; q += blockDim.x) { b[q] = 1.0; m[q] = mi1; }  // prior (targetMap.py:8)
 }
 
 __global__ void __launch_bounds__(128) k_ig_visible(IgDev G, const double* poses, const int32_t* world, double fov,
@@ -259,7 +306,7 @@ __global__ void __launch_bounds__(256) k_ig_update(IgDev G, const double* poses,
         const double px = pose[0], py = pose[1], phi = pose[2];
         ig_visible_block(d2, px, py, phi, fov, range, vis, tid, blockDim.x);
         double s, c;
-        sincos(phi, &s, &c);
+        ig_sincos(phi, &s, &c);
         const int nd = n_det[w * P + p];
         for (int q = tid; q < IG_BEL * IG_BEL; q += blockDim.x) {
             int j = q / IG_BEL, i = q - j * IG_BEL;
@@ -284,6 +331,12 @@ __global__ void __launch_bounds__(256) k_ig_update(IgDev G, const double* poses,
     }
     if (observed)
         for (int j = tid; j < IG_BEL; j += blockDim.x) observed[(size_t)w * IG_BEL + j] = uni[j];
+    // the MI cache follows the belief (only cells seen in this update changed)
+    double* mi = G.mi + (size_t)w * IG_BEL * IG_BEL;
+    for (int q = tid; q < IG_BEL * IG_BEL; q += blockDim.x) {
+        int j = q / IG_BEL, i = q - j * IG_BEL;
+        if ((uni[j] >> i) & 1ull) mi[q] = ig_cell_mi(bel[q]);
+    }
 }
 
 __global__ void __launch_bounds__(256) k_ig_reward(IgDev G, const unsigned long long* masks, const int32_t* world,
@@ -297,7 +350,7 @@ __global__ void __launch_bounds__(256) k_ig_reward(IgDev G, const unsigned long 
     }
     for (int j = tid; j < IG_BEL; j += blockDim.x) m[j] = masks[(size_t)q * IG_BEL + j];
     __syncthreads();
-    double r = ig_reward_block(G.belief + (size_t)world[q] * IG_BEL * IG_BEL, m, red, tid, blockDim.x);
+    double r = ig_reward_block(G.mi + (size_t)world[q] * IG_BEL * IG_BEL, m, red, tid, blockDim.x);
     if (tid == 0) reward[q] = r;
 }
 
@@ -369,7 +422,7 @@ __global__ void __launch_bounds__(128) k_ig_rollouts(IgDev G, const double* pose
         for (int j = tid; j < IG_BEL; j += blockDim.x) observed_out[((size_t)q * nsims + sim) * IG_BEL + j] = obs[j];
     for (int j = tid; j < IG_BEL; j += blockDim.x) obs[j] &= ~exclude[(size_t)q * IG_BEL + j];
     __syncthreads();
-    double r = ig_reward_block(G.belief + (size_t)w * IG_BEL * IG_BEL, obs, red, tid, blockDim.x);
+    double r = ig_reward_block(G.mi + (size_t)w * IG_BEL * IG_BEL, obs, red, tid, blockDim.x);
     if (tid == 0) {
         rewards[(size_t)q * nsims + sim] = r;
         if (final_pose) {

@@ -147,6 +147,12 @@ int cagym_rollout(void* env, int n_steps, int auto_reset, const cagym_outputs* o
 
 int cagym_get_state(void* env, cagym_state_ptrs* out);
 
+/* The per-world episode statistics as ONE packed [N, 6] int32 table, written by one kernel: {bit pattern of the fp32 return
+ * sum, finished episodes, env steps in them, agents at goal / in collision / timed out} - the 24-byte record the multi-GPU
+ * all-gather carries (the reference's per-episode statistics are experiments/src/env_utils.py:41-75).
+ * records: device pointer, N * 6 int32. */
+int cagym_pack_episode_stats(void* env, int32_t* records, void* stream);
+
 /* Name of the kernel instantiation this handle launches for cagym_step / cagym_step_autoreset (rollout == 0) or
  * cagym_rollout (rollout != 0), as rocprofv3 --kernel-trace prints it (bench.py reports it next to the roofline). */
 int cagym_kernel_name(void* env, int rollout, int auto_reset, char* buf, int buf_len);
@@ -189,7 +195,9 @@ int cagym_ga3c_act(void* env, const float* weights, int max_observed, void* work
 int cagym_ig_init(void* env, void* stream);
 /* re-initialise the belief grids of the masked worlds (NULL = all) to the prior. */
 int cagym_ig_reset_belief(void* env, const uint8_t* world_mask, void* stream);
-/* views: edf_d2 [S,300,300] u32 squared cell distances (EDF = sqrt(d2)*0.1), belief [N,60,60] f64 odds. */
+/* READ-ONLY views: edf_d2 [S,300,300] u32 squared cell distances (EDF = sqrt(d2)*0.1), belief [N,60,60] f64 odds.  The belief
+ * changes through cagym_ig_reset_belief / cagym_ig_update_belief only: the library keeps the per-cell mutual information of the
+ * belief beside it (the reward sums of cagym_ig_mi_reward / cagym_ig_rollouts / cagym_dmcts_plan read that cache). */
 int cagym_ig_get(void* env, uint32_t** edf_d2, double** belief);
 /* targetMap.getVisibleCells (targetMap.py:43-84) for Q poses (x, y, phi) of worlds world[q]. */
 int cagym_ig_visible_cells(void* env, const double* poses, const int32_t* world, int Q, double fov_rad,

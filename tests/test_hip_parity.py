@@ -252,6 +252,23 @@ def test_kernel_generations_agree_bitwise(M, wpw, monkeypatch):
     assert int(s1["stat_episodes"].sum()) > 0 or M > 20  # 32 crowded agents need more than T steps to all finish
 
 
+def test_packed_episode_stats_kernel_matches_column_packing():
+    """cagym_pack_episode_stats (one kernel, the record the multi-GPU all-gather carries) == stats.pack_episode_stats."""
+    import torch
+    stats = importlib.import_module("gym-exploration-2d_amd.stats")
+    N, M = 37, 10
+    a6 = scen.random_worlds_fast(3 * N, M, seed=2)
+    e = _hip(N=N, M=M, game_over_mode=1, n_scenarios=3 * N)
+    e.set_scenario(a6, scen.POLICY_RVO, scen.DYN_UNICYCLE, coop=np.full((3 * N, M), 0.5))
+    e.reset()
+    e.env.rollout(400, auto_reset=True)
+    a = e.env.packed_episode_stats()
+    b = stats.pack_episode_stats(e.env.episode_stats())
+    torch.cuda.synchronize()
+    assert a.dtype == torch.int32 and tuple(a.shape) == (N, 6) and torch.equal(a, b)
+    assert int(a[:, 1].sum()) > 0
+
+
 def test_unknown_kernel_generation_is_rejected(monkeypatch):
     """A removed or misspelt kernel generation must not silently run the default one."""
     monkeypatch.setenv("CAGYM_KERNEL", "v2")
