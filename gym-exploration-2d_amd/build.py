@@ -120,7 +120,35 @@ def build_variant(tag, extra=(), verbose=False):
     return lib
 
 
+def build_alt(tag, extra, only):
+    """A/B library csrc/libcagym_hip_<tag>.so: the units whose object name contains one of `only` are recompiled with the
+    extra flags (objects under csrc/build/alt_<tag>/), every other unit is the default build's object.  E.g.
+    build_alt("minw4", ["-DCAGYM_MINW_WIDE=4"], ["k3_256_20_2_0"]).  Select with CAGYM_LIB=<path>."""
+    build()
+    alt = os.path.join(OBJ, "alt_" + tag)
+    os.makedirs(alt, exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "hipcc")
+    objs = []
+    jobs = []
+    for obj, src, defs, _h in units():
+        if any(o in obj for o in only):
+            out = os.path.join(alt, obj)
+            jobs.append([hipcc, "--offload-arch=" + ARCH, "-c"] + FLAGS + defs + list(extra) + ["-o", out, os.path.join(CSRC, src)])
+            objs.append(out)
+        else:
+            objs.append(os.path.join(OBJ, obj))
+    with concurrent.futures.ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 2))) as ex:
+        list(ex.map(subprocess.check_call, jobs))
+    lib = os.path.join(CSRC, "libcagym_hip_%s.so" % tag)
+    tl = _torch_lib_dir()
+    subprocess.check_call(["g++", "-shared", "-o", lib] + objs + ["-L" + tl, "-lamdhip64", "-Wl,-rpath," + tl])
+    return lib
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 3 and sys.argv[1] == "--alt":  # python build.py --alt <tag> <unit-substring> [flags...]
+        print(build_alt(sys.argv[2], sys.argv[4:], [sys.argv[3]]))
+        sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[1] == "--variant":  # python build.py --variant <tag> [flags...]
         print(build_variant(sys.argv[2], sys.argv[3:], verbose=True))
         sys.exit(0)

@@ -335,7 +335,9 @@ __device__ __forceinline__ void publish_pref_velocity3(const Lds3& W, int a) {
 // part repeated on every row lane it was no faster.
 __device__ __forceinline__ void wall_prep3(const CagymDev& D, const Lds3& W, int a, int ko, uint32_t inv_m, int M) {
     const int wl = (int)__umulhi((uint32_t)a, inv_m);
-    const int nrect = ko > 0 ? W.wnob[wl] : D.sc_nobst[W.wsc[wl]];
+    int nrect;  // (an if / else, not `c ? lds : global`: the conditional operator would select between the two ADDRESSES - a flat load)
+    if (ko > 0) nrect = W.wnob[wl];
+    else nrect = D.sc_nobst[W.wsc[wl]];
     WallPrep P = {0, 0, 0ull};
     if ((a - wl * M) < W.wn[wl] && nrect > 0) P = wall_prep(W.tpx[a], W.tpy[a], W.tr[a]);
     reinterpret_cast<int4*>(W.wall)[a] = make_int4(P.cell, P.flags, (int)(P.w & 0xffffffffull), (int)(P.w >> 32));
@@ -1285,7 +1287,10 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
 
 // waves per SIMD the register budget is held to: 4 workgroups per CU for the specialisations whose LP groups hold one
 // half-plane per lane (4096 worlds x 10 agents = 1024 workgroups = 4 per CU must be co-resident), 3 otherwise
-__host__ __device__ constexpr int cagym_min_waves3(int NT, int MT) { return NT > 256 ? 2 : ((MT > 0 && MT <= 10) ? 4 : 3); }
+#ifndef CAGYM_MINW_WIDE
+#define CAGYM_MINW_WIDE 3  /* waves per SIMD held for the specialisations with two half-planes per LP lane (M = 20, generic) */
+#endif
+__host__ __device__ constexpr int cagym_min_waves3(int NT, int MT) { return NT > 256 ? 2 : ((MT > 0 && MT <= 10) ? 4 : CAGYM_MINW_WIDE); }
 
 template <int NT, int MT, int WPWT, bool AUTO_RESET, bool OBST>
 __global__ void __launch_bounds__(NT, OBST ? 2 : cagym_min_waves3(NT, MT)) k_rollout3(CagymDev D, int n_steps, CagymOut out, int any_rvo) {

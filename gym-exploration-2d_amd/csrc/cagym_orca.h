@@ -926,7 +926,9 @@ __device__ inline void orca_lp_group_n(const float4* L, float4* P, int a, int j,
 #pragma unroll
     for (int c = 0; c < LPL; c++) {
         const int q = j + c * GW;
-        l[c] = q < n ? L[(q < no ? q : ko + q - no) * stride + a] : zero4;
+        // (clamped address, not a conditional load: `cond ? *p : zero` makes the compiler select between an LDS and a stack address -
+        // a flat load and 32 bytes of scratch per lane in every OBST kernel; a lane without a line reads row 0 and never uses it)
+        l[c] = L[(q < n ? (q < no ? q : ko + q - no) : 0) * stride + a];
     }
     if (ox * ox + oy * oy > radius * radius) {
         const float inv = 1.0f / sqrtf(ox * ox + oy * oy);

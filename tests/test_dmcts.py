@@ -248,3 +248,79 @@ def test_cfg5_pipeline_on_device_matches_the_reference_statistics():
     assert abs(cum.mean() - rc[:, -1].mean()) < spread, (cum, rc[:, -1])
     assert cum.std() > 0.05  # the worlds really use different random streams
     env.close()
+
+
+@pytest.mark.gpu
+def test_cfg5_pipeline_20_slot_composition():
+    """BASELINE configs[4]'s composition - 20 agent slots: 3 ig_mcts robots (FirstOrderDynamics, planned (v, omega)), 2 static
+    targets, 15 NonCooperative agents - through the whole loop (belief update, MI reward, device Dec-MCTS, M = 20 env kernels),
+    checked three ways: (1) the HIP env equals the CPU oracle env in lock-step under the same planned actions (state <= 1e-9,
+    masks exact); (2) with the 15 NonCooperative agents in the outer ring of the map, far from anything the robots can see or
+    reach, the robots' poses, plans and the cumulative team reward equal those of the 5-agent, 10-slot run with the same
+    seed BIT FOR BIT (the planner sees poses, rasters and beliefs only); (3) the extra agents do move and are observed."""
+    import torch
+    B = importlib.import_module("gym-exploration-2d_amd.batched_env").BatchedCollisionAvoidanceEnv
+    igm = importlib.import_module("gym-exploration-2d_amd.ig")
+    N, T = 6, 6
+    ig5 = np.array([[-5, 0, 16, 0, 1, .5], [0, 0, 16, 0, 1, .5], [5, 0, 16, 0, 1, .5], [6, 12, 0, 0, 1, .2], [-6, -12, 0, 0, 1, .2]])
+
+    def build(M, n_live):
+        a6 = np.zeros((M, 6))
+        a6[:, 4], a6[:, 5], a6[:, 0] = 1.0, 0.1, 1e3 + np.arange(M)
+        a6[:5] = ig5
+        pol = np.full(M, scen.POLICY_NONCOOP, dtype=np.int32)
+        pol[:3] = scen.POLICY_IGMCTS
+        pol[3:5] = scen.POLICY_STATIC
+        dyn = np.full(M, scen.DYN_UNICYCLE, dtype=np.int32)
+        dyn[:5] = scen.DYN_FIRSTORDER
+        for k in range(5, n_live):  # the outer ring below the rectangles: y = -12.5, 2 m apart, walking right at 0.5 m/s
+            x = -14.0 + 2.0 * (k - 5)
+            a6[k] = [x, -12.5, x + 1.5, -12.5, 0.5, 0.2]
+        return a6, pol, dyn
+
+    runs = {}
+    for M, n_live in ((10, 5), (20, 20)):
+        a6, pol, dyn = build(M, n_live)
+        env = B(N, M, max_obstacles=4, game_over_mode="agent0")
+        args = dict(heading0=np.zeros((N, M)), n_agents=[n_live] * N,
+                    obstacles=np.tile(np.array(OBST, dtype=np.float64)[None], (N, 1, 1)), n_obst=[4] * N)
+        env.set_scenarios(np.tile(a6[None], (N, 1, 1)), np.tile(pol[None], (N, 1)), np.tile(dyn[None], (N, 1)), **args)
+        env.reset()
+        cpu = orc.OracleEnv(N=N, M=M, max_obstacles=4, game_over_mode=0)
+        cpu.set_scenario(np.tile(a6[None], (N, 1, 1)), np.tile(pol[None], (N, 1)), np.tile(dyn[None], (N, 1)), **args)
+        cpu.reset()
+        ig = igm.InfoGain(env)
+        planner = dm.DeviceDecMCTSPlanner(ig, 3, radius=0.5, Ntree=5, Nsims=3, horizon=4, c_p=1.0, gamma=0.95, Ncycles=2, seed=3)
+        world = torch.arange(N, dtype=torch.int32, device=env.device)
+        det = torch.zeros((N, 3, 1, 2), dtype=torch.float64, device=env.device)
+        nd = torch.zeros((N, 3), dtype=torch.int32, device=env.device)
+        cum = torch.zeros(N, dtype=torch.float64, device=env.device)
+        ext = torch.zeros((N, M, 2), dtype=torch.float32, device=env.device)
+        poses_log, acts_log = [], []
+        for t in range(T):
+            st = env.state()
+            poses = torch.stack([st["pos_x"][:, :3], st["pos_y"][:, :3], st["heading"][:, :3]], dim=2)
+            obs = ig.update_belief(poses, det, nd)
+            cum = cum + ig.mi_reward(obs, world)
+            actions, _ = planner.plan(poses)
+            ext[:, :3] = actions.float()
+            env.step(ext)
+            cpu.step(ext.double().cpu().numpy())
+            torch.cuda.synchronize()
+            poses_log.append(poses.cpu().numpy().copy())
+            acts_log.append(actions.cpu().numpy().copy())
+            for k in ("pos", "heading", "vel"):  # (1) HIP == oracle under the planned actions
+                d = env.f(k) - cpu.f(k)
+                if k == "heading":
+                    d = (d + np.pi) % (2 * np.pi) - np.pi
+                assert np.abs(d).max() <= 1e-9, (M, k, t)
+            for k in ("is_at_goal", "in_collision", "ran_out_of_time", "is_done", "game_over"):
+                assert (env.u(k) == cpu.u(k)).all(), (M, k, t)
+        runs[M] = (np.array(poses_log), np.array(acts_log), cum.cpu().numpy(), env.f("pos").copy(), env.obs_oas.cpu().numpy().copy())
+        env.close()
+    p10, a10, c10, _, _ = runs[10]
+    p20, a20, c20, pos20, oas20 = runs[20]
+    assert np.array_equal(p10, p20) and np.array_equal(a10, a20) and np.array_equal(c10, c20)  # (2)
+    assert c20.std() > 0 and (c20 > 0).all()
+    assert np.abs(pos20[:, 5:, 0] - (-14.0 + 2.0 * np.arange(15))[None]).min() > 0.25  # (3) the ring agents walked ...
+    assert (oas20[:, 0, :, 9] != 0).sum() == N * 19                                     # ... and robot 0 lists all 19 others
