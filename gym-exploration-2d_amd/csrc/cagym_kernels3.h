@@ -1040,6 +1040,11 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
         STAMP(1);
         PMARK("D_begin");
         // ---- phase D: wave 0 = S1 (_take_action, env.py:287-340) in registers; the other waves = OAS rows of step t-1 ------
+        //      (Round 3 measured two alternatives, both bit-identical and neither kept: S1 stored straight into a second copy of
+        //      the S1 fields, one barrier instead of "barrier, publish, barrier": 3.97 vs 3.92 ms per 512-step launch on the same
+        //      box, VGPRs 128 -> 101; and, on top of that, S1 run by each LP wave right behind its own programs plus a "quiet agents"
+        //      pass on an idle wave: three executions of the S1 instruction stream per workgroup-step, wave-VALU instructions per
+        //      workgroup-step 3 400 -> 4 205, 4.68 ms - the slowest LP wave sets LP + S1 either way.  profiles/r3/ab_pingpong_s1.txt)
         Agent A;
         bool moved = false;
         const bool s1_lane = agent_lane && C.valid && C.active;

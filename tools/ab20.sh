@@ -10,8 +10,8 @@ for rep in 1 2; do
     python - <<PY
 import json
 a, b = json.load(open("gpurun_out/exp/a.json")), json.load(open("gpurun_out/exp/b.json"))
-print("$L", "rep $rep", "20-step launch %.1f us (%.1f M, frac %.4f)" % (a["roofline"]["launch_ms"] * 1e3, a["value"] / 1e6, a["roofline"]["frac"]),
-      "| 512-step %.3f ms (%.1f M, frac %.4f)" % (b["roofline"]["launch_ms"], b["value"] / 1e6, b["roofline"]["frac"]))
+print("$L", "rep $rep", "20-step launch %.1f us by HIP events, %.1f us wall (%.1f M, frac %.4f)" % (a["roofline"]["launch_ms_hip_events"] * 1e3, a["roofline"]["launch_ms"] * 1e3, a["value"] / 1e6, a["roofline"]["frac"]),
+      "| 512-step %.3f ms by HIP events, %.3f wall (%.1f M, frac %.4f)" % (b["roofline"]["launch_ms_hip_events"], b["roofline"]["launch_ms"], b["value"] / 1e6, b["roofline"]["frac"]))
 PY
   done
 done
