@@ -410,24 +410,38 @@ def main():
             barrier()
             tc.append(time.perf_counter() - t0)
         stats_state["collective_ms"] = 1e3 * sorted(tc)[2]
-        stats_state["every"] = 1 << 30  # not during the probe block below
+        stats_state["every"] = 1 << 30  # not during the probe blocks below
     blocks = [timed_block()]
     if world_size > 1:
-        # one block in `every` carries the collective: at most 1 % of the timed time (same value on every rank)
-        ev = max(1, int(-(-stats_state["collective_ms"] * 1e-3 // (0.01 * max(blocks[0][0], 1e-6)))))
+        # one block in `every` carries the collective: at most 1 % of the timed time, priced on the median of five probe
+        # blocks (the first block of a run is slower than the rest); same value on every rank
+        while len(blocks) < 5:
+            blocks.append(timed_block())
+        med = sorted(b[0] for b in blocks)[2]
+        ev = max(1, int(stats_state["collective_ms"] * 1e-3 / (0.01 * max(med, 1e-6))) + 1)
         r = torch.tensor([ev], dtype=torch.int64, device=device)
         dist.all_reduce(r, op=dist.ReduceOp.MAX)
         stats_state["every"] = int(r.item())
-    if args.repeats > 0:
-        repeats = args.repeats
-    else:  # at least 5 blocks; short blocks are repeated until 2 s are on the clock whatever --steps is (same count on every rank)
-        repeats = int(min(50000, max(5, 2.0 / max(blocks[0][0], 1e-6))))
+
+    def more_blocks(n):
+        """rank 0 decides how many more blocks to time (0 = stop); every rank runs the same count"""
         if world_size > 1:
-            r = torch.tensor([repeats], dtype=torch.int64, device=device)
+            r = torch.tensor([n], dtype=torch.int64, device=device)
             dist.broadcast(r, 0)
-            repeats = int(r.item())
-    while len(blocks) < repeats:
-        blocks.append(timed_block())
+            n = int(r.item())
+        for _ in range(n):
+            blocks.append(timed_block())
+        return n
+
+    if args.repeats > 0:
+        more_blocks(max(0, args.repeats - 1))
+    else:  # at least 5 blocks, and short blocks are repeated until the timed blocks cover 2 s whatever --steps is
+        while len(blocks) < 50000:
+            covered = sum(b[0] for b in blocks)
+            med = sorted(b[0] for b in blocks)[len(blocks) // 2]
+            n = max(5 - len(blocks), int((2.0 - covered) / max(med, 1e-6)) + 1 if covered < 2.0 else 0)
+            if more_blocks(min(n, 50000 - len(blocks))) == 0:
+                break
     if world_size > 1:
         gather_stats(env, force=True)  # the final counters
         barrier()

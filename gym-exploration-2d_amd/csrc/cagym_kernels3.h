@@ -197,7 +197,9 @@ struct Lds3 {
     float4* lp3;     // [lpl NT]      linearProgram3 scratch, lpl GW entries per LP group (lpl = 2, 4 with obstacles); the
                      //               obstacle-neighbour sort of phase A borrows it
     double* keys;    // [AS*MP]       OAS sort key (-inf = not observed)
-    double* gap;     // [AS*MP]       d - (r_i + r_j) for the lower index of a pair, else +inf
+    unsigned long long* gmin;  // [AS]    min over the agent's pairs (as the LOWER index, Q7) of d - (r_i + r_j), as an order-preserving
+                     //               64-bit key: every pair lane folds its gap in with ONE LDS ds_min_u64 (a gap MATRIX [AS*MP] and a row
+                     //               scan in S2 before round 3: 3.8 KB of LDS that kept the 5-worlds-per-workgroup variant at 3 per CU)
     uint8_t* hit;    // [AS*MP]       pair collides
 };
 
@@ -208,7 +210,7 @@ __host__ __device__ inline size_t cagym_lds3_head(int AS) {
 // instantiation's extra arrays
 __host__ __device__ inline size_t cagym_lds3_bytes(int M, int AS, int NT, int ko, int lpl, bool obst) {
     const size_t MP = cagym_mp(M);
-    return a16(cagym_lds3_head(AS)) + a16(AS * MP * 8) + (size_t)(ko + M - 1) * AS * 16 + (size_t)lpl * NT * 16 + 2 * AS * MP * 8 + a16(AS * MP) +
+    return a16(cagym_lds3_head(AS)) + a16(AS * MP * 8) + (size_t)(ko + M - 1) * AS * 16 + (size_t)lpl * NT * 16 + AS * MP * 8 + (size_t)AS * 8 + a16(AS * MP) +
            (size_t)(AS / M) * (ko / 2) * 64 +  // staged rectangles: worlds x Kobs x 4 float4
            (obst ? (size_t)(NT / CAGYM_WAVE) * 512 + a16((size_t)ko * AS * 4) + (size_t)AS * 16 : 0);  // OBST: beam lists, coverage bits, wall prep
 }
@@ -245,8 +247,8 @@ __device__ __forceinline__ Lds3 carve_lds3(unsigned char* smem, int M, int AS, i
     W.lp3 = reinterpret_cast<float4*>(u);
     u += (size_t)lpl * NT * 16;
     W.keys = reinterpret_cast<double*>(u);
-    W.gap = W.keys + AS * MP;
-    W.hit = reinterpret_cast<uint8_t*>(W.gap + AS * MP);
+    W.gmin = reinterpret_cast<unsigned long long*>(W.keys + AS * MP);
+    W.hit = reinterpret_cast<uint8_t*>(W.gmin + AS);
     W.rect = reinterpret_cast<float4*>(reinterpret_cast<unsigned char*>(W.hit) + a16(AS * MP));
     W.blist = reinterpret_cast<uint16_t*>(reinterpret_cast<unsigned char*>(W.rect) + (size_t)(AS / M) * (ko / 2) * 64);
     W.cov = reinterpret_cast<uint32_t*>(W.blist + (size_t)(NT / CAGYM_WAVE) * 256);
@@ -526,8 +528,21 @@ __device__ __forceinline__ UPair upair_of(int p, int M) {
     return q;
 }
 
+// order-preserving 64-bit key of a double (no NaN): unsigned order of the keys = order of the doubles
+__device__ __forceinline__ unsigned long long gap_key(double x) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    return b ^ ((b >> 63) ? ~0ull : 0x8000000000000000ull);
+}
+__device__ __forceinline__ double gap_of_key(unsigned long long k) {
+    const unsigned long long b = k ^ ((k >> 63) ? 0x8000000000000000ull : ~0ull);
+    return __longlong_as_double((long long)b);
+}
+#define CAGYM_GAP_INF 0xFFF0000000000000ull  /* gap_key(+inf) */
+
 // ---- phase A body: pair distances of the moved state (env.py:630-655), OAS sort keys, fp32 squared distances ------------
-template <int MT>
+// GAP: fold the pair's gap into the lower agent's running minimum (phase A only: S2 consumes and resets it; the prologue's and the
+// reset path's calls rebuild keys / distances for the NEXT step's half-planes and rows and must leave it alone)
+template <int MT, bool GAP>
 __device__ __forceinline__ void pair_distances3(const CagymDev& D, const Lds3& W, int p, int M, int MP) {
     const UPair q = upair_of<MT>(p, M);
     const int n = W.wn[q.wl];
@@ -553,8 +568,7 @@ __device__ __forceinline__ void pair_distances3(const CagymDev& D, const Lds3& W
     }
     W.hit[lo * MP + shi] = ht;
     W.hit[hi * MP + slo] = ht;
-    W.gap[lo * MP + shi] = gp;
-    W.gap[hi * MP + slo] = INFINITY;
+    if (GAP && gp < INFINITY) atomicMin(&W.gmin[lo], gap_key(gp));  // (no lane waits for the result: ds_min_u64 without return)
     W.keys[lo * MP + shi] = klo;
     W.keys[hi * MP + slo] = khi;
     W.dsq[lo * MP + shi] = make_uint2((uint32_t)shi, __float_as_uint(dq));
@@ -904,6 +918,7 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
             W.tmoved[tid] = 0;
             W.trvo[tid] = live_rvo(A.st, C.valid && C.active);
             W.nobl[tid] = 0;
+            W.gmin[tid] = CAGYM_GAP_INF;
             if (C.wl < C.wpw && C.slot == 0) {
                 W.wn[C.wl] = C.valid ? C.n : 0;
                 W.wsc[C.wl] = C.valid ? (int)(((long long)C.world + (long long)C.episode * D.N) % D.S) : 0;
@@ -911,12 +926,10 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
             // constant entries of the distance / key rows: own slot and the padding
             W.dsq[tid * MP + C.slot] = make_uint2((uint32_t)C.slot, 0x7f800000u);
             W.hit[tid * MP + C.slot] = 0;
-            W.gap[tid * MP + C.slot] = INFINITY;
             W.keys[tid * MP + C.slot] = -INFINITY;
             for (int l = M; l < MP; l++) {
                 W.dsq[tid * MP + l] = make_uint2((uint32_t)l, 0x7f800000u);
                 W.hit[tid * MP + l] = 0;
-                W.gap[tid * MP + l] = INFINITY;
                 W.keys[tid * MP + l] = -INFINITY;
             }
         }
@@ -933,7 +946,7 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
             obstacle_lines_phase3(D, W, M, AS, ko, nagents, inv_m);
         }
         if (any_rvo) {
-            for (int p = tid; p < nup; p += NT) pair_distances3<MT>(D, W, p, M, MP);
+            for (int p = tid; p < nup; p += NT) pair_distances3<MT, false>(D, W, p, M, MP);
             __syncthreads();
             for (int p = tid; p < nup; p += NT) half_planes3<MT, LAZY_RANK && !OBST>(D, W, p, M, MP, AS, ko);
         }
@@ -1126,7 +1139,7 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
         }
         if (OBST && D.map_bits && agent_lane) wall_prep3(D, W, tid, ko, inv_m, M);  // wave 0, beside the last wave's LP inputs
         PMARK("A_pairs_begin");
-        for (int p = tid; p < nup; p += NT) pair_distances3<MT>(D, W, p, M, MP);
+        for (int p = tid; p < nup; p += NT) pair_distances3<MT, true>(D, W, p, M, MP);
         PMARK("A_pairs_end");
         WAVETRACE(t, 8);
         const bool obst_lines = OBST && ko > 0 && any_rvo && t + 1 < n_steps;
@@ -1146,18 +1159,14 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
                 float reward = 0.f;
                 Agent S;
                 S.st = W.tst[tid];
+                const double dmin = gap_of_key(W.gmin[tid]);  // the closest other agent (as the lower index of the pair, Q7), folded by phase A
+                W.gmin[tid] = CAGYM_GAP_INF;                  // ... and consumed: the next step's pair lanes start from +inf
                 if (C.valid && C.active) {
                     S.px = W.tpx[tid]; S.py = W.tpy[tid]; S.r = W.tr[tid];
                     bool coll_wall = false;
-                    double dmin = INFINITY;
                     uint32_t hits = 0;
                     const uint32_t* hrow = reinterpret_cast<const uint32_t*>(W.hit + tid * MP);
-                    const double2* grow = reinterpret_cast<const double2*>(W.gap + tid * MP);
-                    for (int l4 = 0; l4 < MP; l4 += 4) {
-                        hits |= hrow[l4 >> 2];
-                        const double2 g0 = grow[l4 >> 1], g1 = grow[(l4 >> 1) + 1];
-                        dmin = fmin(dmin, fmin(fmin(g0.x, g0.y), fmin(g1.x, g1.y)));
-                    }
+                    for (int l4 = 0; l4 < MP; l4 += 4) hits |= hrow[l4 >> 2];
                     const bool coll_agent = hits != 0;
                     if (OBST && D.map_bits) coll_wall = W.lpk[tid] != 0;  // wall_prep3 / wall_rows3 in phase A
                     double r = -0.01;
@@ -1258,7 +1267,7 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
                     if (any_rvo && more) ego_lp_inputs3<OBST>(D, W, a, M, AS, ko, inv_m);
                 }
             }
-            for (int p = tid; p < nup; p += NT) pair_distances3<MT>(D, W, p, M, MP);
+            for (int p = tid; p < nup; p += NT) pair_distances3<MT, false>(D, W, p, M, MP);
             if (OBST && ko > 0 && any_rvo && more) {
                 __syncthreads();
                 obstacle_lines_phase3(D, W, M, AS, ko, nagents, inv_m);

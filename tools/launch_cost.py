@@ -67,10 +67,7 @@ WG_LIB = os.path.join(b.CSRC, "libcagym_hip_wgtrace.so")
 
 
 def build_wgtrace():
-    tl = os.path.join(os.path.dirname(torch.__file__), "lib")
-    obj = os.path.join(b.CSRC, "cagym_api_wgtrace.o")
-    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-c", "-DCAGYM_WGTRACE"] + b.FLAGS + ["-o", obj, os.path.join(b.CSRC, "cagym_api.hip")])
-    subprocess.check_call(["g++", "-shared", "-o", WG_LIB, obj, "-L" + tl, "-lamdhip64", "-Wl,-rpath," + tl])
+    assert b.build_variant("wgtrace", ["-DCAGYM_WGTRACE"]) == WG_LIB  # one monolithic diagnostic unit, cached (build.py)
 
 
 def part_b():

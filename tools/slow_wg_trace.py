@@ -8,12 +8,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 b = importlib.import_module("gym-exploration-2d_amd.build")
 import torch
-LIB = os.path.join(b.CSRC, "libcagym_hip_slowwg.so")
 if "--child" not in sys.argv:
-    tl = os.path.join(os.path.dirname(torch.__file__), "lib")
-    obj = os.path.join(b.CSRC, "cagym_api_slowwg.o")
-    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-c", "-DCAGYM_WAVETRACE", "-DCAGYM_WGTRACE"] + b.FLAGS + ["-o", obj, os.path.join(b.CSRC, "cagym_api.hip")])
-    subprocess.check_call(["g++", "-shared", "-o", LIB, obj, "-L" + tl, "-lamdhip64", "-Wl,-rpath," + tl])
+    LIB = b.build_variant("slowwg", ["-DCAGYM_WAVETRACE", "-DCAGYM_WGTRACE"])  # one monolithic diagnostic unit, cached (build.py)
     sys.exit(subprocess.call([sys.executable, os.path.abspath(__file__), "--child"], env=dict(os.environ, CAGYM_LIB=LIB)))
 scen = importlib.import_module("gym-exploration-2d_amd.scenarios")
 B = importlib.import_module("gym-exploration-2d_amd.batched_env").BatchedCollisionAvoidanceEnv
