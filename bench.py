@@ -418,7 +418,7 @@ def main():
         while len(blocks) < 5:
             blocks.append(timed_block())
         med = sorted(b[0] for b in blocks)[2]
-        ev = max(1, int(stats_state["collective_ms"] * 1e-3 / (0.01 * max(med, 1e-6))) + 1)
+        ev = max(1, int(stats_state["collective_ms"] * 1e-3 / (0.008 * max(med, 1e-6))) + 1)  # 0.8 % of the probe median: the blocks that follow are a little shorter
         r = torch.tensor([ev], dtype=torch.int64, device=device)
         dist.all_reduce(r, op=dist.ReduceOp.MAX)
         stats_state["every"] = int(r.item())

@@ -67,8 +67,8 @@ open(P + "bench_4096x10_rvo_pmc_hbm.txt", "w").write(
     "driver command (--steps 20 --warmup 5): --kernel-trace --stats average %.4f ms over %s launches of 20 steps\n"
     "(bench_driver_cmd_20steps_kernel_stats.csv); bench.py's HIP-event median %.4f ms (bench_driver_cmd.json)\n" % (
         d0["roofline"]["kernel"], units, f, 2 * f * 1024 / 1e6, w, w * 1024 / 1e6, tot / 1e6, tot / units, 517.0 * units / 1e6,
-        dur(O + "pmc_fetch.txt") / 1e6, dur(O + "pmc_write.txt") / 1e6, float(ks[3]) / 1e6, ks[1], d0["roofline"]["launch_ms"],
-        float(ks20[3]) / 1e6, ks20[1], d20["roofline"]["launch_ms"]))
+        dur(O + "pmc_fetch.txt") / 1e6, dur(O + "pmc_write.txt") / 1e6, float(ks[3]) / 1e6, ks[1], d0["roofline"]["launch_ms_hip_events"],
+        float(ks20[3]) / 1e6, ks20[1], d20["roofline"]["launch_ms_hip_events"]))
 print("traffic B/agent-step %.1f" % (tot / units))
 txt = ["rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_LDS -- python3 bench.py --steps 1024 --warmup 512 --repeats 5 --no-cpu-baseline | ... --steps 20 --warmup 5 --repeats 200",
        "per-dispatch averages (512 / 20 env steps per dispatch at 4096 worlds); SQ_ACTIVE_INST_VALU in quad-cycles summed over SIMDs; GRBM_GUI_ACTIVE summed over the 8 XCDs"]
