@@ -248,7 +248,7 @@ __device__ inline double dm_reward_wave(const double* belief, const unsigned lon
     return __shfl(r, 0, 64);
 }
 
-__global__ void __launch_bounds__(DM_THREADS) k_dmcts_plan(IgDev G, DmParams P, const double* poses, DmNode* nodes, DmMasks* masks,
+__global__ void __launch_bounds__(DM_THREADS, 4) k_dmcts_plan(IgDev G, DmParams P, const double* poses, DmNode* nodes, DmMasks* masks,
                                                          int32_t* n_nodes_all, DmPublished* pub_all, double* out_actions,
                                                          uint8_t* out_paths, double* out_stats) {
     __shared__ unsigned long long vis[IG_BEL], excl[IG_BEL], bobs[IG_BEL];
@@ -323,22 +323,30 @@ __global__ void __launch_bounds__(DM_THREADS) k_dmcts_plan(IgDev G, DmParams P, 
                     __syncthreads();
                 }
                 // ---- selection (DecMCTS.py:14-18, 140-153, 288-289) --------------------------------------------------
-                if (tid == 0) {
+                // (the children of a node are scored side by side on the lanes of wave 0 - a logarithm, a division and a square root
+                //  each; lane 0 alone walked up to 4 levels x 9 children - and the first maximum in child order is taken, as `if u > best`)
+                if (wave == 0) {
                     int node = 0;
-                    while (T[node].nchild > 0) {
+                    for (;;) {
+                        const int nc = T[node].nchild;  // uniform
+                        if (nc <= 0) break;
                         const double n_p = T[node].Nv;
-                        int bi = -1;
-                        double bu = -INFINITY;
-                        for (int k = 0; k < T[node].nchild; k++) {
-                            const DmNode& ch = T[T[node].child0 + k];
-                            double u;
+                        const int c0 = T[node].child0;
+                        double u = -INFINITY;
+                        int bi = lane;
+                        if (lane < nc) {
+                            const DmNode& ch = T[c0 + lane];
                             if (ch.Nv == 0.0) u = INFINITY;
                             else u = n_p > 0.0 ? ch.mu + 2 * P.c_p * sqrt(2 * log(n_p) / ch.Nv) : ch.mu;
-                            if (u > bu) { bu = u; bi = T[node].child0 + k; }
                         }
-                        node = bi;
+                        for (int off = 8; off > 0; off >>= 1) {  // nc <= 9: lanes 0..15
+                            const double u2 = __shfl_down(u, off, 64);
+                            const int i2 = __shfl_down(bi, off, 64);
+                            if (u2 > u || (u2 == u && i2 < bi)) { u = u2; bi = i2; }
+                        }
+                        node = c0 + __shfl(bi, 0, 64);
                     }
-                    sh_sel = node;
+                    if (lane == 0) sh_sel = node;
                 }
                 __syncthreads();
                 const int s = sh_sel;
@@ -426,30 +434,40 @@ __global__ void __launch_bounds__(DM_THREADS) k_dmcts_plan(IgDev G, DmParams P, 
                 // ---- _update_distribution (DecMCTS.py:162-180): top comm_n nodes by mu (first created first on ties),
                 //      those with a roll-out, q = mu^2 -------------------------------------------------------------------------
                 const int total = nn[0];
-                for (int round = 0; round < P.comm_n; round++) {
+                int mypick[DM_MAXCOMM];  // the rounds' winners (uniform: every thread derives them from the waves' candidates)
+#pragma unroll
+                for (int round = 0; round < DM_MAXCOMM; round++) {  // (unrolled to its compile-time bound: mypick stays in registers)
+                    if (round >= P.comm_n) break;
                     double bm = -INFINITY;
                     int bi = 0x7fffffff;
                     for (int i = 1 + tid; i < total; i += DM_THREADS) {
                         bool taken = false;
-                        for (int q = 0; q < round; q++) taken |= picks[q] == i;
+#pragma unroll
+                        for (int q = 0; q < DM_MAXCOMM; q++)
+                            if (q < round) taken |= mypick[q] == i;
                         if (taken) continue;
                         const double m = T[i].mu;
                         if (m > bm || (m == bm && i < bi)) { bm = m; bi = i; }
                     }
-                    red[tid] = bm;
-                    redi[tid] = bi;
-                    __syncthreads();
-                    for (int step = DM_THREADS / 2; step > 0; step >>= 1) {  // arg-max over (mu desc, index asc)
-                        if (tid < step) {
-                            const double m2 = red[tid + step];
-                            const int i2 = redi[tid + step];
-                            if (m2 > red[tid] || (m2 == red[tid] && i2 < redi[tid])) { red[tid] = m2; redi[tid] = i2; }
-                        }
-                        __syncthreads();
+                    // arg-max over (mu desc, index asc): inside the wave by lane shuffles, across the 4 waves through LDS - one
+                    // barrier per round (the block-wide tree reduction took 9)
+                    for (int off = 32; off > 0; off >>= 1) {
+                        const double m2 = __shfl_down(bm, off, 64);
+                        const int i2 = __shfl_down(bi, off, 64);
+                        if (m2 > bm || (m2 == bm && i2 < bi)) { bm = m2; bi = i2; }
                     }
-                    if (tid == 0) picks[round] = redi[0];
+                    double* wr = red + (round & 1) * DM_WAVES;
+                    int* wi = redi + (round & 1) * DM_WAVES;
+                    if (lane == 0) { wr[wave] = bm; wi[wave] = bi; }
                     __syncthreads();
+                    double gm = wr[0];
+                    int gi = wi[0];
+                    for (int q = 1; q < DM_WAVES; q++)
+                        if (wr[q] > gm || (wr[q] == gm && wi[q] < gi)) { gm = wr[q]; gi = wi[q]; }
+                    mypick[round] = gi;
+                    if (tid == 0) picks[round] = gi;
                 }
+                __syncthreads();
                 if (tid == 0) {
                     int cnt = 0;
                     int keep[DM_MAXCOMM];
