@@ -58,6 +58,7 @@ def parse_args(argv=None):
     ap.add_argument("--repeats", type=int, default=0, help="timed blocks (0 = at least 5, more while the blocks are short)")
     ap.add_argument("--per-step-launch", action="store_true", help="one cagym_step_autoreset launch per env step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--halves", type=int, default=1, help="cfg4: split the rank's worlds into this many independent groups, each with its own handle and HIP stream, so that one group's GA3C forward (matrix cores) overlaps another group's env step (vector units); 1 = one group (measured: 0.302 ms with 1, 0.383 with 2, 0.500 with 4 - cagym_ga3c_act costs 78 us for half the worlds, 84 us for all: not kept as default)")
     ap.add_argument("--graph", action="store_true", help="cfg4: replay the step's launches from one captured HIP graph (measured: 0.311 vs 0.303 ms eager - the step is not launch-bound; profiles/r3/cfg4_graph_vs_eager.txt)")
     ap.add_argument("--pool-factor", type=int, default=8, help="scenario pool size = factor x worlds")
     ap.add_argument("--scenarios", default="host", choices=["host", "device"],
@@ -239,9 +240,37 @@ def main():
         launch_mode = "per step: cagym_ga3c_act (device-side selection + state vectors + fused forward, no host sync) + cagym_step_autoreset (laser scan inside)"
         kernel_name = env.kernel_name(rollout=False, auto_reset=True)
 
+        # --halves H > 1: worlds are independent, so the rank's worlds are dealt to H handles, each on its own HIP stream: group A's
+        # GA3C forward (fp32 MFMA) runs beside group B's env kernel (VALU / LDS, two workgroups per CU) instead of after it
+        groups = [(env, ga3c, ext, None)]
+        if args.halves > 1:
+            H = args.halves
+            env.close()
+            groups = []
+            for h in range(H):
+                lo, hi = h * N // H, (h + 1) * N // H
+                sl = np.r_[lo:hi, N + lo:N + hi]  # both pool halves of this group's worlds
+                e_h = BEnv(hi - lo, M, n_scenarios=2 * (hi - lo), max_obstacles=K, laserscan=True, game_over_mode="agent0", device=device)
+                e_h.set_scenarios(a6[sl], pol4[sl], scen.DYN_UNICYCLE, coop=np.full((2 * (hi - lo), M), 0.5), obstacles=ob[sl], n_obst=nob[sl])
+                e_h.reset()
+                groups.append((e_h, GA3C(e_h), torch.zeros((hi - lo, M, 2), dtype=torch.float32, device=device), torch.cuda.Stream(device=device)))
+            env, ga3c, ext = groups[0][0], groups[0][1], groups[0][2]  # statistics / per-kernel timings: the first group (all run the same kernels)
+            launch_mode += "; worlds dealt to %d handles on %d HIP streams (GA3C forward of one group beside the env kernel of another)" % (H, H)
+            torch.cuda.synchronize(device)
+
         def one_step():
-            ga3c.act(ext)
-            env.step(ext, auto_reset=True)
+            if len(groups) == 1:
+                ga3c.act(ext)
+                env.step(ext, auto_reset=True)
+                return
+            main = torch.cuda.current_stream(device)
+            for e_h, g_h, x_h, st_h in groups:
+                st_h.wait_stream(main)
+                with torch.cuda.stream(st_h):
+                    g_h.act(x_h)
+                    e_h.step(x_h, auto_reset=True)
+            for _e, _g, _x, st_h in groups:
+                main.wait_stream(st_h)
 
         # the step is a chain of 4 launches + 1 memset issued from Python: captured once into a HIP graph and replayed
         # (nothing in it allocates or synchronises; same device work, no per-launch host cost)
@@ -279,9 +308,10 @@ def main():
                 return (time.perf_counter() - t0) / reps
             t_nn = loop(lambda: ga3c.act(ext))
             t_env = loop(lambda: env.step(ext, auto_reset=True))
-            return {"ga3c_evals_per_s": N / t_nn, "ga3c_ms_per_step": 1e3 * t_nn, "ga3c_tflops_fp32": N * 0.67e6 / t_nn / 1e12,
-                    "env_kernel_ms_per_step": 1e3 * t_env,
-                    "env_kernel_hbm_frac": balg * N * M / t_env / (HBM_PEAK_GBS * 1e9)}
+            n0 = env.N  # = N, or one group's worlds with --halves
+            return {"ga3c_evals_per_s": n0 / t_nn, "ga3c_ms_per_step": 1e3 * t_nn, "ga3c_tflops_fp32": n0 * 0.67e6 / t_nn / 1e12,
+                    "env_kernel_ms_per_step": 1e3 * t_env, "kernels_timed_alone_on_worlds": n0,
+                    "env_kernel_hbm_frac": balg * n0 * M / t_env / (HBM_PEAK_GBS * 1e9)}
         extra["cfg4"] = cfg4_extra
     else:  # cfg5: env part (3 IG agents driven externally + 2 static targets + 15 NonCooperative) + planner primitives
         IG = importlib.import_module("gym-exploration-2d_amd.ig").InfoGain
