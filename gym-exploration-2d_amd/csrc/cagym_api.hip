@@ -132,7 +132,7 @@ inline int n_wg2(const Env* e) {
 // obst: the OBST instantiation (worlds may hold rectangles); lines: RVO agents among them (obstacle half-plane rows)
 inline size_t lds3_bytes(const Env* e, bool obst, bool lines) {
     const int M = e->cfg.max_agents;
-    return cagym_lds3_bytes(M, cagym_as(M, wpw_spec(e)), spec2(e).nt, (obst && lines) ? 2 * e->cfg.max_obstacles : 0, cagym_lpl3(spec2(e).mt, obst), obst);
+    return cagym_lds3_bytes(M, cagym_as(M, wpw_spec(e)), spec2(e).nt, (obst && lines) ? 2 * e->cfg.max_obstacles : 0, cagym_lpl3(spec2(e).mt, obst), obst, spec2(e).mt);
 }
 inline bool has_map(const Env* e) { return e->cfg.max_obstacles > 0; }
 inline size_t scan_bytes(const Env* e) { return (size_t)e->cfg.n_worlds * e->cfg.max_agents * 16 * sizeof(float); }
@@ -265,6 +265,12 @@ int cagym_create(const cagym_config* cfg, void** env_out) {
         int lds3 = (int)lds3_bytes(e, false, false), lds3_obst = (int)lds3_bytes(e, true, true);
         if (lds3_obst > 160 * 1024) lds3_obst = (int)lds3_bytes(e, true, false);  // too many rectangles for RVO agents: refused at set_scenarios
         if (e->generation == 3 && lds3 > 160 * 1024) e->generation = 1;
+        // the free-space kernels keep the neighbour keys in the LP scratch (cagym_dsq_aliased): it must hold them
+        if (e->generation == 3 && cagym_dsq_aliased(false, spec2(e).mt) &&
+            (size_t)cagym_as((int)M, wpw_spec(e)) * cagym_mp((int)M) * 8 > (size_t)cagym_lpl3(spec2(e).mt, false) * spec2(e).nt * 16) {
+            cagym_destroy(e);
+            return fail(nullptr, CAGYM_E_UNSUPPORTED, "neighbour keys do not fit the LP scratch of this specialisation");
+        }
         if (!k3_entry(e)) { cagym_destroy(e); return fail(nullptr, CAGYM_E_UNSUPPORTED, "no kernel specialisation for this shape"); }
         k3_entry(e)->setattr[0](lds3);
         if (lds3_obst <= 160 * 1024) k3_entry(e)->setattr[1](lds3_obst);

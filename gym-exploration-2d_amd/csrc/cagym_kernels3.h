@@ -203,19 +203,33 @@ struct Lds3 {
     uint8_t* hit;    // [AS*MP]       pair collides
 };
 
+// The ORCA neighbour keys are only alive between phase A (pair lanes write them) and phase B (the half-plane lanes rank with them); the
+// LP scratch only in phase C.  The free-space kernels therefore keep both in the same LDS bytes (M = 20: 43.5 -> 37.1 KB, a fourth
+// workgroup per CU); the OBST kernels borrow the scratch for their obstacle-neighbour lists in phase A and keep them apart, and so does the
+// -DCAGYM_LP_UPFRONT alternative (its LP groups rank inside phase C).
+// Only where it buys a workgroup (two half-planes per LP lane: M = 20 and the run-time-M kernels): the M <= 10 kernels sit exactly at 128
+// VGPRs and the three extra stores per step cost them a spill.
+__host__ __device__ constexpr bool cagym_dsq_aliased(bool obst, int MT) {
+#ifdef CAGYM_LP_UPFRONT
+    return false;
+#else
+    return !obst && cagym_two3(MT);
+#endif
+}
 __host__ __device__ inline size_t cagym_lds3_head(int AS) {
     return (size_t)20 * AS * 8 + AS * 8 + (size_t)6 * AS * 4 + 96 * 4 + 8 * 4 + (size_t)2 * AS * 8 + (size_t)3 * AS * 4;
 }
 // ko: rows of `sorted` reserved for obstacle lines; lpl: LP scratch per group in units of GW float4 (cagym_lpl3); obst: the OBST
 // instantiation's extra arrays
-__host__ __device__ inline size_t cagym_lds3_bytes(int M, int AS, int NT, int ko, int lpl, bool obst) {
+__host__ __device__ inline size_t cagym_lds3_bytes(int M, int AS, int NT, int ko, int lpl, bool obst, int MT) {
     const size_t MP = cagym_mp(M);
-    return a16(cagym_lds3_head(AS)) + a16(AS * MP * 8) + (size_t)(ko + M - 1) * AS * 16 + (size_t)lpl * NT * 16 + AS * MP * 8 + (size_t)AS * 8 + a16(AS * MP) +
+    // (free space: the neighbour keys `dsq` live in the LP scratch - written in phase A, read in phase B, the scratch is phase C's)
+    return a16(cagym_lds3_head(AS)) + (cagym_dsq_aliased(obst, MT) ? 0 : a16(AS * MP * 8)) + (size_t)(ko + M - 1) * AS * 16 + (size_t)lpl * NT * 16 + AS * MP * 8 + (size_t)AS * 8 + a16(AS * MP) +
            (size_t)(AS / M) * (ko / 2) * 64 +  // staged rectangles: worlds x Kobs x 4 float4
            (obst ? (size_t)(NT / CAGYM_WAVE) * 512 + a16((size_t)ko * AS * 4) + (size_t)AS * 16 : 0);  // OBST: beam lists, coverage bits, wall prep
 }
 
-__device__ __forceinline__ Lds3 carve_lds3(unsigned char* smem, int M, int AS, int NT, int ko = 0, int lpl = 2) {
+__device__ __forceinline__ Lds3 carve_lds3(unsigned char* smem, int M, int AS, int NT, int ko, int lpl, bool obst, int MT) {
     Lds3 W;
     const size_t MP = cagym_mp(M);
     W.tpx = reinterpret_cast<double*>(smem);
@@ -240,11 +254,14 @@ __device__ __forceinline__ Lds3 carve_lds3(unsigned char* smem, int M, int AS, i
     W.wnob = W.wsc + 32;
     W.flag = W.wnob + 32;
     unsigned char* u = smem + a16(cagym_lds3_head(AS));
-    W.dsq = reinterpret_cast<uint2*>(u);
-    u += a16(AS * MP * 8);
+    if (!cagym_dsq_aliased(obst, MT)) {
+        W.dsq = reinterpret_cast<uint2*>(u);
+        u += a16(AS * MP * 8);
+    }
     W.sorted = reinterpret_cast<float4*>(u);
     u += (size_t)(ko + M - 1) * AS * 16;
     W.lp3 = reinterpret_cast<float4*>(u);
+    if (cagym_dsq_aliased(obst, MT)) W.dsq = reinterpret_cast<uint2*>(u);  // AS * MP * 8 <= lpl * NT * 16 for every specialisation (checked by cagym_create)
     u += (size_t)lpl * NT * 16;
     W.keys = reinterpret_cast<double*>(u);
     W.gmin = reinterpret_cast<unsigned long long*>(W.keys + AS * MP);
@@ -893,7 +910,7 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
 #else
     constexpr bool LAZY_RANK = false;
 #endif
-    const Lds3 W = carve_lds3(smem, M, AS, NT, ko, LPL);
+    const Lds3 W = carve_lds3(smem, M, AS, NT, ko, LPL, OBST, MT);
     LaneCtx C = make_ctx2(D, M, WPWT ? WPWT : CAGYM_WAVE / M);
     const uint32_t inv_m = (uint32_t)(0x100000000ull / (uint32_t)M) + 1u;
     const int nagents = C.wpw * M;               // agent slots of this workgroup (<= 64: wave 0)
@@ -1138,6 +1155,10 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
             WAVETRACE(t, 7);
         }
         if (OBST && D.map_bits && agent_lane) wall_prep3(D, W, tid, ko, inv_m, M);  // wave 0, beside the last wave's LP inputs
+        if (cagym_dsq_aliased(OBST, MT) && agent_lane) {  // the key rows share their bytes with the LP scratch: own slot and padding again
+            W.dsq[tid * MP + C.slot] = make_uint2((uint32_t)C.slot, 0x7f800000u);
+            for (int l = M; l < MP; l++) W.dsq[tid * MP + l] = make_uint2((uint32_t)l, 0x7f800000u);
+        }
         PMARK("A_pairs_begin");
         for (int p = tid; p < nup; p += NT) pair_distances3<MT, true>(D, W, p, M, MP);
         PMARK("A_pairs_end");
@@ -1302,7 +1323,7 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
 // waves per SIMD the register budget is held to: 4 workgroups per CU for the specialisations whose LP groups hold one
 // half-plane per lane (4096 worlds x 10 agents = 1024 workgroups = 4 per CU must be co-resident), 3 otherwise
 #ifndef CAGYM_MINW_WIDE
-#define CAGYM_MINW_WIDE 3  /* waves per SIMD held for the specialisations with two half-planes per LP lane (M = 20, generic) */
+#define CAGYM_MINW_WIDE 4  /* waves per SIMD held for the specialisations with two half-planes per LP lane (M = 20, generic) */
 #endif
 __host__ __device__ constexpr int cagym_min_waves3(int NT, int MT) { return NT > 256 ? 2 : ((MT > 0 && MT <= 10) ? 4 : CAGYM_MINW_WIDE); }
 
