@@ -319,14 +319,20 @@ __device__ __forceinline__ void orca_clip_by(const float4 ln, const float4 mine,
         else ltl = fmaxf(ltl, t);
     }
 }
-template <int GW, bool TWO>
-__device__ __forceinline__ bool orca_lp1_group(const float4 ln, const float4 m0, bool take0, const float4 m1, bool take1,
-                                               float radius, float ox, float oy, bool dir_opt, float& rx, float& ry) {
+// The chord of a line in the disc of radius `radius` (linearProgram1's first lines): (tLeft, tRight) = -dot -+ sqrt(disc), or
+// (+inf, -inf) when the line misses the disc (disc < 0: "return false" - the empty interval fails the tLeft > tRight test instead).
+// It depends on the line alone: the lane that owns a line computes it ONCE (round 3) and the group fetches it by lane shuffle in
+// every round that projects onto that line, instead of every lane recomputing dot, disc and a correctly rounded sqrt per round.
+__device__ __forceinline__ float2 orca_chord(const float4 ln, float radius) {
     const float dot = ln.x * ln.z + ln.y * ln.w;
     const float disc = dot * dot + radius * radius - (ln.x * ln.x + ln.y * ln.y);
-    if (disc < 0.0f) return false;
+    if (disc < 0.0f) return make_float2(INFINITY, -INFINITY);
     const float sq = sqrtf(disc);
-    float tl = -dot - sq, tr = -dot + sq;
+    return make_float2(-dot - sq, -dot + sq);
+}
+template <int GW, bool TWO>
+__device__ __forceinline__ bool orca_lp1_group(const float4 ln, float tl, float tr, const float4 m0, bool take0, const float4 m1, bool take1,
+                                               float ox, float oy, bool dir_opt, float& rx, float& ry) {
     float ltl = -INFINITY, ltr = INFINITY;
     if (!TWO) {
         if (take0) {  // one candidate per lane: plain selects
@@ -418,6 +424,9 @@ __device__ inline void orca_lp_group(const float4* L, float4* P, int a, int j, i
         rx = ox;
         ry = oy;
     }
+    // the chords of the lane's own lines (the second one only where lines GW .. 2 GW - 1 can be projected onto often: with at most GW + 1
+    // lines the one line beyond the lanes - the farthest neighbour - computes its chord in the rare round that needs it)
+    const float2 c0 = orca_chord(l0, radius), c1 = TWO ? orca_chord(l1, radius) : make_float2(0.f, 0.f);
     asm volatile("" :: "v"(l0.x), "v"(rx));
     LPWT(13);
     // linearProgram2.  The reference walks the lines in order and projects onto each violated one; between two
@@ -433,7 +442,17 @@ __device__ inline void orca_lp_group(const float4* L, float4* P, int a, int j, i
         const int i = __ffs((int)m) - 1;
         LPCOUNT(c_lp2);
         const float4 li = L[i * stride + a];
-        if (!orca_lp1_group<GW, TWO>(li, l0, j < i, l1, j + GW < i, radius, ox, oy, false, rx, ry)) {
+        const int own = gbase + (i & (GW - 1));  // the lane of the group that owns line i (slot i / GW)
+        float tl0, tr0;
+        if (!TWO && i >= GW) {  // group-uniform
+            const float2 ci = orca_chord(li, radius);
+            tl0 = ci.x;
+            tr0 = ci.y;
+        } else {
+            tl0 = __shfl((TWO && i >= GW) ? c1.x : c0.x, own, 64);
+            tr0 = __shfl((TWO && i >= GW) ? c1.y : c0.y, own, 64);
+        }
+        if (!orca_lp1_group<GW, TWO>(li, tl0, tr0, l0, j < i, l1, j + GW < i, ox, oy, false, rx, ry)) {
             fail = i;  // result keeps the value it had before this line (tempResult)
             break;
         }
@@ -456,13 +475,14 @@ __device__ inline void orca_lp_group(const float4* L, float4* P, int a, int j, i
         // projected lines of lane j (those of its half-planes that come before i); `have` = it exists
         bool have0 = false, have1 = false;
         float4 p0 = zero4, p1 = zero4;
+        float2 pc0 = make_float2(0.f, 0.f), pc1 = make_float2(0.f, 0.f);  // chords of the lane's projected lines
         if (j < i) {
             have0 = orca_project(li, l0, p0);
-            if (have0) P[j] = p0;
+            if (have0) { P[j] = p0; pc0 = orca_chord(p0, radius); }
         }
         if (TWO && j + GW < i) {
             have1 = orca_project(li, l1, p1);
-            if (have1) P[j + GW] = p1;
+            if (have1) { P[j + GW] = p1; pc1 = orca_chord(p1, radius); }
         }
         const float px = -li.w, py = li.z;
         const float tx = rx, ty = ry;
@@ -478,7 +498,9 @@ __device__ inline void orca_lp_group(const float4* L, float4* P, int a, int j, i
             kcur = k + 1;
             LPCOUNT(c_lp3i);
             const float4 pk = P[k];  // projected line k (same wave: the LDS write above is ordered before this read)
-            if (!orca_lp1_group<GW, TWO>(pk, p0, j < k && have0, p1, j + GW < k && have1, radius, px, py, true, qx, qy)) {
+            const int ownk = gbase + (k & (GW - 1));
+            const float tlk = __shfl((TWO && k >= GW) ? pc1.x : pc0.x, ownk, 64), trk = __shfl((TWO && k >= GW) ? pc1.y : pc0.y, ownk, 64);
+            if (!orca_lp1_group<GW, TWO>(pk, tlk, trk, p0, j < k && have0, p1, j + GW < k && have1, px, py, true, qx, qy)) {
                 failed = true;
                 break;
             }
