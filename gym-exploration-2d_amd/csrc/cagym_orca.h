@@ -912,13 +912,9 @@ __device__ __forceinline__ uint64_t orca_group_mask(const bool (&v)[LPL], int gb
     return m;
 }
 template <int GW, int LPL>
-__device__ __forceinline__ bool orca_lp1_group_n(const float4 ln, const float4 (&mine)[LPL], const bool (&take)[LPL], float radius,
+__device__ __forceinline__ bool orca_lp1_group_n(const float4 ln, float tl, float tr, const float4 (&mine)[LPL], const bool (&take)[LPL],
                                                  float ox, float oy, bool dir_opt, float& rx, float& ry) {
-    const float dot = ln.x * ln.z + ln.y * ln.w;
-    const float disc = dot * dot + radius * radius - (ln.x * ln.x + ln.y * ln.y);
-    if (disc < 0.0f) return false;
-    const float sq = sqrtf(disc);
-    float tl = -dot - sq, tr = -dot + sq;
+    // (tl, tr): the chord of ln in the disc, from the lane that owns the line (orca_chord); (+inf, -inf) = the line misses the disc
     float ltl = -INFINITY, ltr = INFINITY;
 #pragma unroll
     for (int c = 0; c < LPL; c++)
@@ -938,6 +934,16 @@ __device__ __forceinline__ bool orca_lp1_group_n(const float4 ln, const float4 (
     ry = ln.y + t * ln.w;
     return true;
 }
+// the chord of line q of the solve, held by lane q % GW in slot q / GW, fetched by every lane of the group
+template <int GW, int LPL>
+__device__ __forceinline__ float2 orca_group_chord(const float2 (&c)[LPL], int q, int gbase) {
+    const int slot = q / GW, own = gbase + (q & (GW - 1));
+    float sx = c[0].x, sy = c[0].y;
+#pragma unroll
+    for (int k = 1; k < LPL; k++)
+        if (slot == k) { sx = c[k].x; sy = c[k].y; }
+    return make_float2(__shfl(sx, own, 64), __shfl(sy, own, 64));
+}
 template <int GW, int LPL>
 __device__ inline void orca_lp_group_n(const float4* L, float4* P, int a, int j, int no, int nn, int ko, float radius, float ox,
                                        float oy, float& rx, float& ry, int stride, int* lp3_flag = nullptr) {
@@ -952,6 +958,9 @@ __device__ inline void orca_lp_group_n(const float4* L, float4* P, int a, int j,
         // a flat load and 32 bytes of scratch per lane in every OBST kernel; a lane without a line reads row 0 and never uses it)
         l[c] = L[(q < n ? (q < no ? q : ko + q - no) : 0) * stride + a];
     }
+    float2 ch[LPL];  // the chords of the lane's own lines, once (every round that projects onto a line fetches its chord by shuffle)
+#pragma unroll
+    for (int c = 0; c < LPL; c++) ch[c] = orca_chord(l[c], radius);
     if (ox * ox + oy * oy > radius * radius) {
         const float inv = 1.0f / sqrtf(ox * ox + oy * oy);
         rx = ox * inv * radius;
@@ -975,7 +984,8 @@ __device__ inline void orca_lp_group_n(const float4* L, float4* P, int a, int j,
         bool take[LPL];
 #pragma unroll
         for (int c = 0; c < LPL; c++) take[c] = j + c * GW < i;
-        if (!orca_lp1_group_n<GW, LPL>(li, l, take, radius, ox, oy, false, rx, ry)) {
+        const float2 ci = orca_group_chord<GW, LPL>(ch, i, gbase);
+        if (!orca_lp1_group_n<GW, LPL>(li, ci.x, ci.y, l, take, ox, oy, false, rx, ry)) {
             fail = i;
             break;
         }
@@ -999,17 +1009,20 @@ __device__ inline void orca_lp_group_n(const float4* L, float4* P, int a, int j,
         // COMPACTED in RVO2 (skipped "parallel, same direction" lines leave no hole); order and membership are all that
         // linearProgram2 depends on, so holes (have = false) are simply never selected here.
         float4 p[LPL];
+        float2 pch[LPL];  // chords of the projected set (an obstacle line keeps its own)
         bool have[LPL];
 #pragma unroll
         for (int c = 0; c < LPL; c++) {
             const int q = j + c * GW;
             have[c] = false;
             p[c] = zero4;
+            pch[c] = ch[c];
             if (q < no) {
                 p[c] = l[c];
                 have[c] = true;
             } else if (q < i) {
                 have[c] = orca_project(li, l[c], p[c]);
+                if (have[c]) pch[c] = orca_chord(p[c], radius);
             }
             if (have[c]) P[q] = p[c];
         }
@@ -1033,7 +1046,8 @@ __device__ inline void orca_lp_group_n(const float4* L, float4* P, int a, int j,
             bool take[LPL];
 #pragma unroll
             for (int c = 0; c < LPL; c++) take[c] = have[c] && j + c * GW < k;
-            if (!orca_lp1_group_n<GW, LPL>(pk, p, take, radius, px, py, true, qx, qy)) {
+            const float2 ck = orca_group_chord<GW, LPL>(pch, k, gbase);
+            if (!orca_lp1_group_n<GW, LPL>(pk, ck.x, ck.y, p, take, px, py, true, qx, qy)) {
                 failed = true;
                 break;
             }
