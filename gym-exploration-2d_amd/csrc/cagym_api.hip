@@ -258,7 +258,7 @@ int cagym_create(const cagym_config* cfg, void** env_out) {
             int cus = 256;
             if (hipGetDeviceProperties(&prop, e->cfg.device) == hipSuccess && prop.multiProcessorCount > 0)
                 cus = prop.multiProcessorCount;
-            e->wpw10 = (e->cfg.n_worlds + 3) / 4 <= 4 * cus ? 4 : 5;  // 4 workgroups per CU fit (110 VGPRs, 38.6 KB LDS)
+            e->wpw10 = (e->cfg.n_worlds + 3) / 4 <= 4 * cus ? 4 : 5;  // 4 workgroups per CU fit (128 VGPRs; 30.4 KB of LDS with 4 worlds, 37.7 KB with 5)
             const char* w = getenv("CAGYM_WPW10");  // diagnostics
             if (w && (w[0] == '4' || w[0] == '5')) e->wpw10 = w[0] - '0';
         }
