@@ -176,3 +176,36 @@ def test_laserscan_on_a_handle_without_rectangles_reads_zero():
     traj = e.env.rollout(T, auto_reset=True, out=buf)
     torch.cuda.synchronize()
     assert float(traj["laserscan"].abs().max()) == 0.0
+
+
+def test_refused_set_scenarios_leaves_the_handle_as_it_was():
+    """cagym_set_scenarios validates before it commits: a refused call (n_obst out of range, rectangles announced but not given,
+    a degenerate rectangle among RVO agents) must leave the pool, the obstacle half-plane capacity and the RVO flags of the handle
+    untouched - the next steps equal those of a handle that never saw the bad call."""
+    import torch
+    N, M, K, T = 12, 6, 3, 30
+    rng = np.random.default_rng(5)
+    a6, ob, nob, _ = scen.obstacle_worlds(N, M, K, seed=21)
+    pol = np.full((N, M), scen.POLICY_RVO, dtype=np.int32)
+    a, b = (_hip(N=N, M=M, max_obstacles=K, game_over_mode=1, laserscan=True) for _ in range(2))
+    for e in (a, b):
+        e.set_scenario(a6, pol, scen.DYN_UNICYCLE, coop=np.full((N, M), 0.5), obstacles=ob, n_obst=nob)
+        e.reset()
+    bad_n = nob.copy()
+    bad_n[3] = K + 2                                   # n_obst out of range
+    with pytest.raises(Exception):
+        a.set_scenario(a6, pol, scen.DYN_UNICYCLE, coop=np.full((N, M), 0.5), obstacles=ob, n_obst=bad_n)
+    deg = ob.copy()
+    deg[1, 0] = (1.0, 1.0, 1.0, 2.0)                   # xl == xu: degenerate rectangle among RVO agents
+    with pytest.raises(Exception):
+        a.set_scenario(a6, pol, scen.DYN_UNICYCLE, coop=np.full((N, M), 0.5), obstacles=deg, n_obst=np.maximum(nob, 1))
+    # a pool WITHOUT RVO agents that is refused must not switch the obstacle half-planes off either
+    with pytest.raises(Exception):
+        a.set_scenario(a6, np.full((N, M), scen.POLICY_NONCOOP, dtype=np.int32), scen.DYN_UNICYCLE, obstacles=ob, n_obst=bad_n)
+    for t in range(T):
+        a.env.step()
+        b.env.step()
+        for k in ("reward", "flags", "game_over", "obs_oas", "obs_laser"):
+            assert torch.equal(getattr(a.env, k), getattr(b.env, k)), (k, t)
+    for k in ("pos_x", "pos_y", "heading", "status"):
+        assert torch.equal(a.env.state()[k], b.env.state()[k]), k
