@@ -59,6 +59,7 @@ def parse_args(argv=None):
     ap.add_argument("--per-step-launch", action="store_true", help="one cagym_step_autoreset launch per env step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--halves", type=int, default=1, help="cfg4: split the rank's worlds into this many independent groups, each with its own handle and HIP stream, so that one group's GA3C forward (matrix cores) overlaps another group's env step (vector units); 1 = one group (measured: 0.302 ms with 1, 0.383 with 2, 0.500 with 4 - cagym_ga3c_act costs 78 us for half the worlds, 84 us for all: not kept as default)")
+    ap.add_argument("--max-obstacles", type=int, default=10, help="cfg4: rectangles per world are drawn from 2..this (BASELINE: 10); occupancy experiments only")
     ap.add_argument("--graph", action="store_true", help="cfg4: replay the step's launches from one captured HIP graph (measured: 0.311 vs 0.303 ms eager - the step is not launch-bound; profiles/r3/cfg4_graph_vs_eager.txt)")
     ap.add_argument("--pool-factor", type=int, default=8, help="scenario pool size = factor x worlds")
     ap.add_argument("--scenarios", default="host", choices=["host", "device"],
@@ -223,7 +224,7 @@ def main():
         # agent 0 GA3C-CADRL (state kernel + fused forward kernel per step) + 9 RVO agents among 2-10 rectangles,
         # LaserScan on every agent (scanned inside the step launch), game over when agent 0 is done, auto-reset
         GA3C = importlib.import_module("gym-exploration-2d_amd.ga3c").GA3CCADRLPolicy
-        K = 10
+        K = args.max_obstacles
         S = 2 * N
         a6, ob, nob, _ = scen.obstacle_worlds(S, M, K, seed=1234 + 7919 * rank)
         pol4 = np.full((S, M), scen.POLICY_RVO, dtype=np.int32)

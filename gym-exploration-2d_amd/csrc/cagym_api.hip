@@ -171,6 +171,9 @@ inline void launch3(const Env* e, bool rollout, bool auto_reset, const float* ex
     K3Launch L;
     L.D = e->D; L.ext = ext; L.out = o; L.n_steps = n_steps; L.any_rvo = e->any_rvo; L.rollout = rollout; L.auto_reset = auto_reset;
     L.grid = (unsigned)n_wg2(e); L.lds = lds3_bytes(e); L.stream = st;
+#ifdef CAGYM_DIAG_LDS_PAD  // occupancy experiments only (tools/README.md): unused LDS bytes on top, to force fewer workgroups per CU
+    if (const char* pad = getenv("CAGYM_LDS_PAD")) L.lds += (size_t)atoi(pad);
+#endif
     k3_entry(e)->launch[has_map(e) ? 1 : 0](L);
 }
 
@@ -259,6 +262,20 @@ int cagym_create(const cagym_config* cfg, void** env_out) {
             if (hipGetDeviceProperties(&prop, e->cfg.device) == hipSuccess && prop.multiProcessorCount > 0)
                 cus = prop.multiProcessorCount;
             e->wpw10 = (e->cfg.n_worlds + 3) / 4 <= 4 * cus ? 4 : 5;  // 4 workgroups per CU fit (128 VGPRs; 30.4 KB of LDS with 4 worlds, 37.7 KB with 5)
+            if (has_map(e) && e->wpw10 == 5) {
+                // worlds with rectangles (OBST instantiation, 135 VGPRs: at most 3 workgroups per CU): 4 worlds per workgroup when their
+                // smaller LDS footprint buys a workgroup per CU (cfg4: 53.4 KB -> 3 per CU, 65.9 KB with 5 worlds -> 2;
+                // profiles/r3/cfg4_occupancy_ab.txt)
+                auto per_cu = [&](int wpw) {
+                    e->wpw10 = wpw;
+                    size_t b = lds3_bytes(e, true, true);
+                    if (b > 160 * 1024) b = lds3_bytes(e, true, false);
+                    const int n = (int)((size_t)160 * 1024 / b);
+                    return n < 3 ? n : 3;
+                };
+                const int n4 = per_cu(4), n5 = per_cu(5);
+                e->wpw10 = n4 > n5 ? 4 : 5;
+            }
             const char* w = getenv("CAGYM_WPW10");  // diagnostics
             if (w && (w[0] == '4' || w[0] == '5')) e->wpw10 = w[0] - '0';
         }
@@ -272,6 +289,9 @@ int cagym_create(const cagym_config* cfg, void** env_out) {
             return fail(nullptr, CAGYM_E_UNSUPPORTED, "neighbour keys do not fit the LP scratch of this specialisation");
         }
         if (!k3_entry(e)) { cagym_destroy(e); return fail(nullptr, CAGYM_E_UNSUPPORTED, "no kernel specialisation for this shape"); }
+#ifdef CAGYM_DIAG_LDS_PAD
+        if (const char* pad = getenv("CAGYM_LDS_PAD")) { lds3 += atoi(pad); lds3_obst += atoi(pad); }
+#endif
         k3_entry(e)->setattr[0](lds3);
         if (lds3_obst <= 160 * 1024) k3_entry(e)->setattr[1](lds3_obst);
     }

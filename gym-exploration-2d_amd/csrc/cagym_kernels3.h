@@ -219,14 +219,25 @@ __host__ __device__ constexpr bool cagym_dsq_aliased(bool obst, int MT) {
 __host__ __device__ inline size_t cagym_lds3_head(int AS) {
     return (size_t)20 * AS * 8 + AS * 8 + (size_t)6 * AS * 4 + 96 * 4 + 8 * 4 + (size_t)2 * AS * 8 + (size_t)3 * AS * 4;
 }
+// The OBST instantiation's phase-A-only arrays live in bytes that are dead in phase A (cfg4: 61.1 -> 53.4 KB, a THIRD workgroup per CU:
+// env kernel 229 -> 17x us, profiles/r3/cfg4_occupancy_ab.txt).  Dead between the linear programs (phase C) and the half-plane lanes
+// (phase B): the agent rows [ko, ko + M - 1) of `sorted` - they take the coverage bits and the wall-test records - and, directly behind
+// them, the LP scratch - it already lends its head to the obstacle-neighbour lists (13 B per (ego, candidate)) and now its tail to the
+// neighbour keys `dsq` (alive from phase A's pair lanes to phase B's ranking; the scratch is phase C's).  Only when everything fits.
+__host__ __device__ inline bool cagym_obst_alias(int M, int AS, int NT, int ko, int lpl) {
+    const size_t MP = cagym_mp(M);
+    return a16((size_t)ko * AS * 4) + (size_t)AS * 16 <= (size_t)(M - 1) * AS * 16 &&
+           a16((size_t)13 * ko * AS) + (size_t)AS * MP * 8 <= (size_t)lpl * NT * 16;
+}
 // ko: rows of `sorted` reserved for obstacle lines; lpl: LP scratch per group in units of GW float4 (cagym_lpl3); obst: the OBST
 // instantiation's extra arrays
 __host__ __device__ inline size_t cagym_lds3_bytes(int M, int AS, int NT, int ko, int lpl, bool obst, int MT) {
     const size_t MP = cagym_mp(M);
+    const bool oa = obst && cagym_obst_alias(M, AS, NT, ko, lpl);
     // (free space: the neighbour keys `dsq` live in the LP scratch - written in phase A, read in phase B, the scratch is phase C's)
-    return a16(cagym_lds3_head(AS)) + (cagym_dsq_aliased(obst, MT) ? 0 : a16(AS * MP * 8)) + (size_t)(ko + M - 1) * AS * 16 + (size_t)lpl * NT * 16 + AS * MP * 8 + (size_t)AS * 8 + a16(AS * MP) +
+    return a16(cagym_lds3_head(AS)) + ((cagym_dsq_aliased(obst, MT) || oa) ? 0 : a16(AS * MP * 8)) + (size_t)(ko + M - 1) * AS * 16 + (size_t)lpl * NT * 16 + AS * MP * 8 + (size_t)AS * 8 + a16(AS * MP) +
            (size_t)(AS / M) * (ko / 2) * 64 +  // staged rectangles: worlds x Kobs x 4 float4
-           (obst ? (size_t)(NT / CAGYM_WAVE) * 512 + a16((size_t)ko * AS * 4) + (size_t)AS * 16 : 0);  // OBST: beam lists, coverage bits, wall prep
+           (obst ? (size_t)(NT / CAGYM_WAVE) * 512 + (oa ? 0 : a16((size_t)ko * AS * 4) + (size_t)AS * 16) : 0);  // OBST: beam lists (+ coverage bits, wall prep)
 }
 
 __device__ __forceinline__ Lds3 carve_lds3(unsigned char* smem, int M, int AS, int NT, int ko, int lpl, bool obst, int MT) {
@@ -253,8 +264,9 @@ __device__ __forceinline__ Lds3 carve_lds3(unsigned char* smem, int M, int AS, i
     W.wsc = W.wn + 32;
     W.wnob = W.wsc + 32;
     W.flag = W.wnob + 32;
+    const bool oa = obst && cagym_obst_alias(M, AS, NT, ko, lpl);
     unsigned char* u = smem + a16(cagym_lds3_head(AS));
-    if (!cagym_dsq_aliased(obst, MT)) {
+    if (!cagym_dsq_aliased(obst, MT) && !oa) {
         W.dsq = reinterpret_cast<uint2*>(u);
         u += a16(AS * MP * 8);
     }
@@ -262,13 +274,14 @@ __device__ __forceinline__ Lds3 carve_lds3(unsigned char* smem, int M, int AS, i
     u += (size_t)(ko + M - 1) * AS * 16;
     W.lp3 = reinterpret_cast<float4*>(u);
     if (cagym_dsq_aliased(obst, MT)) W.dsq = reinterpret_cast<uint2*>(u);  // AS * MP * 8 <= lpl * NT * 16 for every specialisation (checked by cagym_create)
+    if (oa) W.dsq = reinterpret_cast<uint2*>(u + a16((size_t)13 * ko * AS));  // behind obstacle_lines_phase3's lists
     u += (size_t)lpl * NT * 16;
     W.keys = reinterpret_cast<double*>(u);
     W.gmin = reinterpret_cast<unsigned long long*>(W.keys + AS * MP);
     W.hit = reinterpret_cast<uint8_t*>(W.gmin + AS);
     W.rect = reinterpret_cast<float4*>(reinterpret_cast<unsigned char*>(W.hit) + a16(AS * MP));
     W.blist = reinterpret_cast<uint16_t*>(reinterpret_cast<unsigned char*>(W.rect) + (size_t)(AS / M) * (ko / 2) * 64);
-    W.cov = reinterpret_cast<uint32_t*>(W.blist + (size_t)(NT / CAGYM_WAVE) * 256);
+    W.cov = oa ? reinterpret_cast<uint32_t*>(W.sorted + (size_t)ko * AS) : reinterpret_cast<uint32_t*>(W.blist + (size_t)(NT / CAGYM_WAVE) * 256);
     W.wall = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(W.cov) + a16((size_t)ko * AS * 4));
     return W;
 }
@@ -911,6 +924,7 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
     constexpr bool LAZY_RANK = false;
 #endif
     const Lds3 W = carve_lds3(smem, M, AS, NT, ko, LPL, OBST, MT);
+    const bool dsq_shared = OBST ? cagym_obst_alias(M, AS, NT, ko, LPL) : cagym_dsq_aliased(false, MT);  // the neighbour keys live in the LP scratch
     LaneCtx C = make_ctx2(D, M, WPWT ? WPWT : CAGYM_WAVE / M);
     const uint32_t inv_m = (uint32_t)(0x100000000ull / (uint32_t)M) + 1u;
     const int nagents = C.wpw * M;               // agent slots of this workgroup (<= 64: wave 0)
@@ -1155,7 +1169,7 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
             WAVETRACE(t, 7);
         }
         if (OBST && D.map_bits && agent_lane) wall_prep3(D, W, tid, ko, inv_m, M);  // wave 0, beside the last wave's LP inputs
-        if (cagym_dsq_aliased(OBST, MT) && agent_lane) {  // the key rows share their bytes with the LP scratch: own slot and padding again
+        if (dsq_shared && agent_lane) {  // the key rows share their bytes with the LP scratch: own slot and padding again
             W.dsq[tid * MP + C.slot] = make_uint2((uint32_t)C.slot, 0x7f800000u);
             for (int l = M; l < MP; l++) W.dsq[tid * MP + l] = make_uint2((uint32_t)l, 0x7f800000u);
         }
