@@ -58,9 +58,19 @@ __device__ unsigned long long g_wgtrace[CAGYM_WGTRACE_MAXWG * CAGYM_WGTRACE_W];
         if (threadIdx.x == 0 && blockIdx.x < CAGYM_WGTRACE_MAXWG)                                           \
             g_wgtrace[blockIdx.x * CAGYM_WGTRACE_W + 39] += (unsigned long long)(cnt) << 8;                 \
     } while (0)
+// sub-phases of a ONE-step launch (tools/cfg4_timeline.py): slots 20.. are free when n_steps == 1
+#define WGTRACE1(slot) do { if (n_steps == 1) WGTRACE(slot); } while (0)
+// lane 0 of wave 1 (the laser chunks of a one-step launch run on waves 1..)
+#define WGTRACE_W1(slot)                                                                                    \
+    do {                                                                                                    \
+        if (threadIdx.x == 64 && blockIdx.x < CAGYM_WGTRACE_MAXWG)                                          \
+            g_wgtrace[blockIdx.x * CAGYM_WGTRACE_W + (slot)] = __builtin_amdgcn_s_memrealtime();            \
+    } while (0)
 #else
+#define WGTRACE_W1(slot) do { } while (0)
 #define WGTRACE(slot) do { } while (0)
 #define WGTRACE_BUSY(cnt) do { } while (0)
+#define WGTRACE1(slot) do { } while (0)
 #endif
 
 // Third diagnostic build (-DCAGYM_WAVETRACE, tools/wave_trace.py): lane 0 of EVERY WAVE of one workgroup stamps s_memtime at
@@ -179,11 +189,12 @@ struct Lds3 {
     int* wsc;      // [32] scenario of the world's current episode (rectangles, raster)
     int* wnob;     // [32] rectangles of that scenario
     float4* rect;  // [worlds x Kobs x 4] the worlds' prepared rectangles (OBST only), staged at episode start
-    uint16_t* blist;  // [waves x 256] (OBST only) a wave's list of the laser beams that can meet a rectangle
+    uint16_t* blist;  // [AS x 16] u16 + [AS x 16] u8 + [16] u8 (OBST only) the workgroup's list of the laser beams that can meet a rectangle, their sample ranges, beams per pass
     uint32_t* cov;    // [ko][AS] (OBST only) obstacle_lines_phase3's coverage bit matrix
     int* wall;        // [4 AS] (OBST only) wall_prep3's per-agent cell / window / row half-widths
-    int* flag;     // [8]  0: a world was reset this step   1: OAS row chunks claimed   2: LP waves finished
-                   //      3/4: some ego needed linearProgram3 this / the previous step
+    int* flag;     // [16] 0: a world was reset this step   1: OAS row chunks claimed   2: LP waves finished
+                   //      3/4: some ego needed linearProgram3 this / the previous step   5/6: obstacle_lines_phase3's work list
+                   //      7, 8, 10: LaserScan: slab-test passes claimed / finished, sampling rounds claimed
     float2* lpv;   // [AS] preferred (optimisation) velocity of each ego
     float2* lpc;   // [AS] pref velocity clipped to maxSpeed = LP start; LP result afterwards
     float* lpr;    // [AS] maxSpeed of the ego (LP radius)
@@ -217,7 +228,7 @@ __host__ __device__ constexpr bool cagym_dsq_aliased(bool obst, int MT) {
 #endif
 }
 __host__ __device__ inline size_t cagym_lds3_head(int AS) {
-    return (size_t)20 * AS * 8 + AS * 8 + (size_t)6 * AS * 4 + 96 * 4 + 8 * 4 + (size_t)2 * AS * 8 + (size_t)3 * AS * 4;
+    return (size_t)20 * AS * 8 + AS * 8 + (size_t)6 * AS * 4 + 96 * 4 + 16 * 4 + (size_t)2 * AS * 8 + (size_t)3 * AS * 4;
 }
 // The OBST instantiation's phase-A-only arrays live in bytes that are dead in phase A (cfg4: 61.1 -> 53.4 KB, a THIRD workgroup per CU:
 // env kernel 229 -> 17x us, profiles/r3/cfg4_occupancy_ab.txt).  Dead between the linear programs (phase C) and the half-plane lanes
@@ -237,7 +248,7 @@ __host__ __device__ inline size_t cagym_lds3_bytes(int M, int AS, int NT, int ko
     // (free space: the neighbour keys `dsq` live in the LP scratch - written in phase A, read in phase B, the scratch is phase C's)
     return a16(cagym_lds3_head(AS)) + ((cagym_dsq_aliased(obst, MT) || oa) ? 0 : a16(AS * MP * 8)) + (size_t)(ko + M - 1) * AS * 16 + (size_t)lpl * NT * 16 + AS * MP * 8 + (size_t)AS * 8 + a16(AS * MP) +
            (size_t)(AS / M) * (ko / 2) * 64 +  // staged rectangles: worlds x Kobs x 4 float4
-           (obst ? (size_t)(NT / CAGYM_WAVE) * 512 + (oa ? 0 : a16((size_t)ko * AS * 4) + (size_t)AS * 16) : 0);  // OBST: beam lists (+ coverage bits, wall prep)
+           (obst ? a16((size_t)AS * 48 + 16) + (oa ? 0 : a16((size_t)ko * AS * 4) + (size_t)AS * 16) : 0);  // OBST: beam list (+ coverage bits, wall prep)
 }
 
 __device__ __forceinline__ Lds3 carve_lds3(unsigned char* smem, int M, int AS, int NT, int ko, int lpl, bool obst, int MT) {
@@ -281,7 +292,7 @@ __device__ __forceinline__ Lds3 carve_lds3(unsigned char* smem, int M, int AS, i
     W.hit = reinterpret_cast<uint8_t*>(W.gmin + AS);
     W.rect = reinterpret_cast<float4*>(reinterpret_cast<unsigned char*>(W.hit) + a16(AS * MP));
     W.blist = reinterpret_cast<uint16_t*>(reinterpret_cast<unsigned char*>(W.rect) + (size_t)(AS / M) * (ko / 2) * 64);
-    W.cov = oa ? reinterpret_cast<uint32_t*>(W.sorted + (size_t)ko * AS) : reinterpret_cast<uint32_t*>(W.blist + (size_t)(NT / CAGYM_WAVE) * 256);
+    W.cov = oa ? reinterpret_cast<uint32_t*>(W.sorted + (size_t)ko * AS) : reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(W.blist) + a16((size_t)AS * 48 + 16));
     W.wall = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(W.cov) + a16((size_t)ko * AS * 4));
     return W;
 }
@@ -441,6 +452,7 @@ __device__ inline void obstacle_lines_phase3(const CagymDev& D, const Lds3& W, i
         }
     }
     __syncthreads();
+    WGTRACE(33);
     OBSTAMP(0);
     if (tid >= NTT - CAGYM_WAVE) {
         // the (ego, candidate) pairs of the whole workgroup as one dense list (the next sub-steps are rounds of full waves): every ego
@@ -464,8 +476,12 @@ __device__ inline void obstacle_lines_phase3(const CagymDev& D, const Lds3& W, i
         if (a == CAGYM_WAVE - 1) { W.flag[5] = incl; W.flag[6] = mx; }
     }
     __syncthreads();
+    WGTRACE(34);
     OBSTAMP(9);
     const int ntodo = W.flag[5], nmax = W.flag[6];
+#ifdef CAGYM_WGTRACE
+    if (threadIdx.x == 0 && blockIdx.x < CAGYM_WGTRACE_MAXWG) g_wgtrace[blockIdx.x * CAGYM_WGTRACE_W + 37] = (unsigned long long)(ntodo | (nmax << 16));
+#endif
     for (int q = tid; q < ntodo; q += NTT) {
         const int a = todo[q] >> 8, i = todo[q] & 255;
         const int n = W.nobl[a];
@@ -487,6 +503,7 @@ __device__ inline void obstacle_lines_phase3(const CagymDev& D, const Lds3& W, i
         todo[q] = (a << 8) | rank;  // (only this lane reads or writes entry q)
     }
     __syncthreads();
+    WGTRACE(35);
     OBSTAMP(10);
     for (int w = tid; w < ntodo * nmax; w += NTT) {
         const int q = w / nmax, sidx = w - q * nmax;
@@ -502,6 +519,7 @@ __device__ inline void obstacle_lines_phase3(const CagymDev& D, const Lds3& W, i
             __hip_atomic_fetch_or(&cov[r * AS + a], 1u << sidx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     __syncthreads();
+    WGTRACE(36);
     OBSTAMP(11);
     if (tid >= NTT - CAGYM_WAVE) {
         const int a = tid - (NTT - CAGYM_WAVE);
@@ -770,6 +788,10 @@ __device__ __forceinline__ void ego_obs3(const CagymDev& D, const Lds3& W, float
 // LaserScanSensor.sense restricted to the samples klo..khi of beam b (every sample outside can be shown not to hit): the running
 // hit count of sensors/LaserScanSensor.py:45-58 only changes at hits, so "the last sample whose count is 1" is sample 15 when
 // exactly one hit lies in the interval, the sample before the second hit when there are more, none without a hit.
+#ifndef CAGYM_LASER_BATCH_ROLLOUT
+#define CAGYM_LASER_BATCH_ROLLOUT 4  /* gathers in flight per sampled beam in the roll-out kernels (register limit); the one-step kernel keeps 8 */
+#endif
+template <int BATCH>
 __device__ __forceinline__ float laserscan_beam_range(const uint32_t* map, double px, double py, double h, double radius, int b,
                                                       int klo, int khi) {
     int egx, egy;
@@ -779,41 +801,85 @@ __device__ __forceinline__ float laserscan_beam_range(const uint32_t* map, doubl
     const double ang0 = b == 15 ? kPi : (double)b * astep + (-kPi);
     double sa, ca;
     sincos(ang0 + h, &sa, &ca);
-    int count = 0, last = -1;
-    for (int k = klo; k <= khi; k++) {
-        const double rg = 0.0 + (double)k * rstep;
-        const double x = px + rg * ca, y = py + rg * sa;
-        int gx, gy;
-        bool in = world_to_cell(x, y, gx, gy);
-        if (in && ego_in) {
-            const double dx = (double)(gy - egy), dy = (double)(gx - egx);
-            in = !(dx * dx + dy * dy < r2);
+    // the raster words are requested BATCH at a time before the first one is looked at (the raster is L2-resident and a gather's
+    // latency is ~1000 cycles: sample after sample, a wave's 44 listed beams took 7.5 us; all sixteen at once cost the OBST roll-out
+    // kernels their registers); the hits of the interval become a 16-bit mask
+    uint32_t hits = 0u;
+#pragma unroll
+    for (int half = 0; half < 16 / BATCH; half++) {
+        uint32_t word[BATCH];
+        int sh[BATCH];
+        uint32_t valid = 0u;
+#pragma unroll
+        for (int q = 0; q < BATCH; q++) {
+            const int k = half * BATCH + q;
+            bool in = k >= klo && k <= khi;
+            int gx = 0, gy = 0;
+            if (in) {
+                const double rg = 0.0 + (double)k * rstep;
+                const double x = px + rg * ca, y = py + rg * sa;
+                in = world_to_cell(x, y, gx, gy);
+                if (in && ego_in) {
+                    const double dx = (double)(gy - egy), dy = (double)(gx - egx);
+                    in = !(dx * dx + dy * dy < r2);
+                }
+            }
+            valid |= in ? (1u << q) : 0u;
+            sh[q] = gy & 31;
+            word[q] = map[in ? gx * CAGYM_MAPW + (gy >> 5) : 0];  // unconditional, clamped address
         }
-        const bool hit = in && map_bit(map, gx, gy);
-        count += hit ? 1 : 0;
-        if (count == 1) last = k;
+#pragma unroll
+        for (int q = 0; q < BATCH; q++) hits |= (((word[q] >> sh[q]) & (valid >> q)) & 1u) << (half * BATCH + q);
+    }
+    // "the last sample whose running hit count is 1": the sample before the second hit, or the beam's last sample when only one hits
+    int count = hits ? 1 : 0, last = -1;
+    if (hits) {
+        const uint32_t rest = hits & (hits - 1u);
+        last = rest ? (int)__builtin_ctz(rest) - 1 : 15;
+        count = rest ? 2 : 1;
     }
     if (count == 1) last = 15;  // no further hit beyond the interval: the count stays 1 to the end of the beam
     const double range = last >= 0 ? 0.0 + (double)last * rstep : 6.0;
     return (float)(1 - range / 6);
 }
 
-// LaserScan of 16 agent slots (256 beams) by one wave.  An occupied raster cell reaches at most one cell (0.1 m) beyond its
-// rectangle, so a beam whose segment misses every rectangle of the world inflated by 0.25 m reads 0.0 (= 1 - 6/6) without looking
-// at the raster, and a beam that meets some only needs the samples inside those crossings.  Four cheap passes (fp32 slab test
-// against the staged rectangles) compact the beams that need the raster into the wave's list; the fp64 sampling then runs on
-// dense lanes.  A rectangle that leaves the map (numpy's negative-index wrap puts its cells elsewhere) or unstaged rectangles
-// (no RVO agent among them: ko == 0) disable the shortcut: every beam of the world is sampled in full.
-__device__ __forceinline__ void laser_chunk3(const CagymDev& D, const Lds3& W, float* laser_out, int chunk, int M, int wpw, uint32_t inv_m, int ko) {
-    const int lane = threadIdx.x & (CAGYM_WAVE - 1), wave = threadIdx.x / CAGYM_WAVE;
-    uint16_t* lst = W.blist + wave * 256;
+// LaserScan of every agent slot of the workgroup, by whichever waves call it (each at its own time; no barrier inside).  An occupied
+// raster cell reaches at most one cell (0.1 m) beyond its rectangle, so a beam whose segment misses every rectangle of the world
+// inflated by 0.25 m reads 0.0 (= 1 - 6/6) without looking at the raster, and a beam that meets some only needs the samples inside
+// those crossings.  Part 1, claimed in wave-passes of 4 agents x 16 beams: fp32 slab test of the beam against the staged rectangles;
+// the beams that need the raster go to the pass's 64 entries of ONE list of the workgroup.  Part 2, once every pass is in (LDS counter,
+// release / acquire): the fp64 sampling in rounds of 64 LISTED beams - a round costs the same ~1 000 instructions whether 20 or 64 of
+// its lanes hold a beam, so the rounds must be dense: per-wave lists (round 2, 16 agents each) needed 5 rounds per workgroup where
+// 150 listed beams fill 3 (cfg4: B phase 14.4 -> x us, tools/cfg4_timeline.py).  A rectangle that leaves the map (numpy's negative-index
+// wrap puts its cells elsewhere) or unstaged rectangles (no RVO agent among them: ko == 0) disable the shortcut: every beam of the
+// world is sampled in full.  Counters W.flag[7..10] must be zero on entry of the first wave (publish step, reset path).
+template <int BATCH>
+__device__ __forceinline__ void laser_scan3(const CagymDev& D, const Lds3& W, float* laser_out, int M, int wpw, int AS, uint32_t inv_m, int ko) {
+    const int lane = threadIdx.x & (CAGYM_WAVE - 1);
+    uint16_t* lst = W.blist;                                      // (agent slot << 4) | beam
+    uint8_t* rng = reinterpret_cast<uint8_t*>(W.blist + AS * 16);  // (first sample << 4) | last sample
     const float rstep = (float)(2 * kPi / 16), reach = 15.0f * rstep + 0.05f, infl = 0.25f;
-    int n = 0;
-    for (int pass = 0; pass < 4; pass++) {
-        const int al = pass * 4 + (lane >> 4), a = chunk * 16 + al, b = lane & 15;
+    uint8_t* cnt = rng + AS * 16;                                  // [passes] beams listed by each pass (pass c owns entries c * 64 ..)
+    const int nag = wpw * M, npass = (nag + 3) / 4;
+    WGTRACE_W1(29);
+    // (ONE lane-0 region per iteration, at its top: "the pass I just finished is in" (release: a wave's LDS operations complete in
+    // order) and the next claim.  With a second `if (lane == 0)` atomic at the END of the body the compiled loop gained an inner
+    // loop between the claim and the body that peeled lane 0 off and re-entered the body with claim 0 for the other lanes (visible
+    // in the ISA), and the wait below never ended.)
+    bool finished_one = false;
+    for (;;) {
+        int c = 0;
+        if (lane == 0) {
+            if (finished_one) __hip_atomic_fetch_add(&W.flag[8], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            c = __hip_atomic_fetch_add(&W.flag[7], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        c = __builtin_amdgcn_readfirstlane(c);
+        if (c >= npass) break;
+        finished_one = true;
+        const int a = c * 4 + (lane >> 4), b = lane & 15;
         bool need = false;
         int klo = 0, khi = 15;
-        if (a < wpw * M) {
+        if (a < nag) {
             const int wl = (int)__umulhi((uint32_t)a, inv_m);
             const int slot = a - wl * M;
             const int world = blockIdx.x * wpw + wl;
@@ -828,13 +894,14 @@ __device__ __forceinline__ void laser_chunk3(const CagymDev& D, const Lds3& W, f
                         __sincosf((float)(ang0 + W.th[a]), &sa, &ca);
                         const float px = (float)W.tpx[a], py = (float)W.tpy[a];
                         const float icx = 1.0f / ca, icy = 1.0f / sa;
+                        const float pxl = px + infl, pxu = px - infl, pyl = py + infl, pyu = py - infl;  // (the test is conservative by 0.15 m: roundings do not matter)
                         float tlo = INFINITY, thi = -INFINITY;
                         const float4* R = W.rect + (size_t)wl * D.Kobs * 4;
                         for (int k = 0; k < W.wnob[wl]; k++) {
                             const float4 r = R[4 * k];
                             if (R[4 * k + 3].y != 1.0f) { tlo = 0.f; thi = reach; continue; }  // leaves the map: no shortcut
-                            const float tx1 = (r.x - infl - px) * icx, tx2 = (r.z + infl - px) * icx;
-                            const float ty1 = (r.y - infl - py) * icy, ty2 = (r.w + infl - py) * icy;
+                            const float tx1 = (r.x - pxl) * icx, tx2 = (r.z - pxu) * icx;
+                            const float ty1 = (r.y - pyl) * icy, ty2 = (r.w - pyu) * icy;
                             const float t1 = fmaxf(fmaxf(fminf(tx1, tx2), fminf(ty1, ty2)), 0.f);
                             const float t2 = fminf(fminf(fmaxf(tx1, tx2), fmaxf(ty1, ty2)), reach);
                             if (t1 <= t2) { tlo = fminf(tlo, t1); thi = fmaxf(thi, t2); }
@@ -852,44 +919,67 @@ __device__ __forceinline__ void laser_chunk3(const CagymDev& D, const Lds3& W, f
             }
         }
         const unsigned long long m = __ballot(need);
-        if (need) lst[n + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)((al << 12) | (b << 8) | (klo << 4) | khi);
-        n += __popcll(m);
+        if (need) {
+            const int i = c * CAGYM_WAVE + __popcll(m & ((1ull << lane) - 1ull));
+            lst[i] = (uint16_t)((a << 4) | b);
+            rng[i] = (uint8_t)((klo << 4) | khi);
+        }
+        cnt[c] = (uint8_t)__popcll(m);  // (every lane stores the same byte: no branch)
     }
-    for (int base = 0; base < n; base += CAGYM_WAVE) {  // (a wave's LDS accesses complete in order: the list is its own)
-        if (base + lane < n) {
-            const int e = lst[base + lane];
-            const int a = chunk * 16 + (e >> 12), b = (e >> 8) & 15;
+    WGTRACE_W1(30);
+    // every pass was claimed by some wave that is running it now (bounded wait; nobody waits for a wave that never calls)
+    while (__hip_atomic_load(&W.flag[8], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < npass) __builtin_amdgcn_s_sleep(1);
+    int n = 0;
+    for (int q = 0; q < npass; q++) n += cnt[q];
+#ifdef CAGYM_WGTRACE
+    if (threadIdx.x == 64 && blockIdx.x < CAGYM_WGTRACE_MAXWG) g_wgtrace[blockIdx.x * CAGYM_WGTRACE_W + 32] = (unsigned long long)n;
+#endif
+    for (;;) {
+        int r = 0;
+        if (lane == 0) r = __hip_atomic_fetch_add(&W.flag[10], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        r = __builtin_amdgcn_readfirstlane(r);
+        if (r * CAGYM_WAVE >= n) break;
+        int i = r * CAGYM_WAVE + lane;  // index into the concatenation of the passes' lists
+        if (i < n) {
+            int q = 0;
+            for (; q < npass; q++) {  // (at most 16 passes; the counts are broadcast reads)
+                const int cq = cnt[q];
+                if (i < cq) break;
+                i -= cq;
+            }
+            const int e = lst[q * CAGYM_WAVE + i], kk = rng[q * CAGYM_WAVE + i];
+            const int a = e >> 4, b = e & 15;
             const int wl = (int)__umulhi((uint32_t)a, inv_m);
             const int slot = a - wl * M;
             const int world = blockIdx.x * wpw + wl;
             const uint32_t* map = D.map_bits + (size_t)W.wsc[wl] * CAGYM_MAPD * CAGYM_MAPW;
-            laser_out[((size_t)world * M + slot) * 16 + b] = laserscan_beam_range(map, W.tpx[a], W.tpy[a], W.th[a], W.tr[a], b, (e >> 4) & 15, e & 15);
+            laser_out[((size_t)world * M + slot) * 16 + b] = laserscan_beam_range<BATCH>(map, W.tpx[a], W.tpy[a], W.th[a], W.tr[a], b, kk >> 4, kk & 15);
         }
     }
+    WGTRACE_W1(31);
 }
 
 // claim-and-process loop of the observation workers: chunks 0 .. nck-1 are 64 directed pairs each, chunk nck is the
-// scalar-observation store of the agent slots, chunks nck+1 .. are 16 agents x 16 laser beams each (when asked for).  Every wave of the workgroup may call it; a wave leaves when the
-// counter has run past the last chunk (every wave reaches that: the counter only grows).
-template <bool OBST>
+// scalar-observation store of the agent slots; the LaserScan (when asked for) follows behind them (laser_scan3 has its own
+// claim counters).  Every wave of the workgroup may call it; a wave leaves the chunk loop when the counter has run past the
+// last chunk (every wave reaches that: the counter only grows).
+template <bool OBST, int BATCH = 8>
 __device__ __forceinline__ void observation_chunks3(const CagymDev& D, const Lds3& W, const CagymOut& o, int npairs, int M, int MP,
-                                                    int K, int wpw, int worlds_valid, uint32_t inv_m, int ko = 0) {
+                                                    int K, int wpw, int worlds_valid, uint32_t inv_m, int ko = 0, int AS = 0) {
     const int lane = threadIdx.x & (CAGYM_WAVE - 1);
     const int nck = (npairs + CAGYM_WAVE - 1) / CAGYM_WAVE;
-    const int nlaser = (OBST && o.laserscan) ? (wpw * M + 15) / 16 : 0;
     for (;;) {
         int c = 0;
         if (lane == 0) c = __hip_atomic_fetch_add(&W.flag[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         c = __builtin_amdgcn_readfirstlane(c);
-        if (c > nck + nlaser) break;
+        if (c > nck) break;
         if (c < nck) {
             if (o.obs_oas) oas_row3(W, o.obs_oas, c * CAGYM_WAVE + lane, npairs, M, MP, K, wpw, worlds_valid, inv_m);
-        } else if (c == nck) {
+        } else {
             ego_obs3(D, W, o.obs_ego, lane, M, wpw, inv_m);
-        } else if (OBST) {
-            laser_chunk3(D, W, o.laserscan, c - nck - 1, M, wpw, inv_m, ko);
         }
     }
+    if (OBST && o.laserscan) laser_scan3<BATCH>(D, W, o.laserscan, M, wpw, AS, inv_m, ko);
 }
 
 __device__ __forceinline__ CagymOut out_slice3(const CagymOut& out, int t, size_t N, size_t NM, int M) {
@@ -907,7 +997,8 @@ __device__ __forceinline__ CagymOut out_slice3(const CagymOut& out, int t, size_
 // OBST: the handle's worlds may hold rectangles (max_obstacles > 0): wall test, LaserScan, and - when RVO agents live among
 // them (D.ko > 0) - obstacle half-planes with LP groups of 4 half-planes per lane.  The free-space instantiation carries
 // none of that code (it cost the headline kernel 7 VGPRs and a spill).
-template <int NT, int MT, int WPWT, bool AUTO_RESET, bool OBST>
+// ONE: the one-step launch (k_step3: n_steps == 1 at compile time)
+template <int NT, int MT, int WPWT, bool AUTO_RESET, bool OBST, bool ONE = false>
 __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const float* ext, const CagymOut& out, int n_steps,
                                   bool any_rvo) {
     constexpr int NWAVES = NT / CAGYM_WAVE;
@@ -964,21 +1055,25 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
                 W.keys[tid * MP + l] = -INFINITY;
             }
         }
-        if (tid < 8) W.flag[tid] = 0;
+        if (tid < 16) W.flag[tid] = 0;
         __syncthreads();
+        WGTRACE1(20);
         if (OBST && ko > 0) {
             stage_rects3(D, W, C.wpw, C.worlds_valid);
             __syncthreads();
         }
+        WGTRACE1(21);
         if (agent_lane && any_rvo) ego_lp_inputs3<OBST>(D, W, tid, M, AS, ko, inv_m);
         else if (agent_lane) publish_pref_velocity3(W, tid);
         if (OBST && ko > 0 && any_rvo) {
             __syncthreads();
             obstacle_lines_phase3(D, W, M, AS, ko, nagents, inv_m);
         }
+        WGTRACE1(22);
         if (any_rvo) {
             for (int p = tid; p < nup; p += NT) pair_distances3<MT, false>(D, W, p, M, MP);
             __syncthreads();
+            WGTRACE1(23);
             for (int p = tid; p < nup; p += NT) half_planes3<MT, LAZY_RANK && !OBST>(D, W, p, M, MP, AS, ko);
         }
         __syncthreads();
@@ -1082,6 +1177,7 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
                 __hip_atomic_fetch_add(&W.flag[2], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         STAMP(1);
+        WGTRACE1(24);
         PMARK("D_begin");
         // ---- phase D: wave 0 = S1 (_take_action, env.py:287-340) in registers; the other waves = OAS rows of step t-1 ------
         //      (Round 3 measured two alternatives, both bit-identical and neither kept: S1 stored straight into a second copy of
@@ -1139,7 +1235,7 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
             __builtin_amdgcn_s_setprio(0);
 #endif
             PMARK("D_rows_begin");
-            observation_chunks3<OBST>(D, W, o_prev, npairs, M, MP, K, C.wpw, C.worlds_valid, inv_m, ko);
+            observation_chunks3<OBST, (ONE ? 8 : CAGYM_LASER_BATCH_ROLLOUT)>(D, W, o_prev, npairs, M, MP, K, C.wpw, C.worlds_valid, inv_m, ko, AS);
 #ifndef CAGYM_NO_LAG_PRIORITY
             if (lagging) __builtin_amdgcn_s_setprio(3);
             else __builtin_amdgcn_s_setprio(1);
@@ -1148,6 +1244,7 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
         }
         PMARK("D_end_barrierX");
         __syncthreads();  // rows of step t-1 are out: the moved state may replace the old one
+        WGTRACE1(25);
         WAVETRACE(t, 5);
         if (s1_lane) {
             lds3_store_s1(W, A, tid);
@@ -1156,8 +1253,9 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
         } else if (agent_lane) {
             W.tmoved[tid] = 0;
         }
-        if (tid == NT - 1) { W.flag[1] = 0; W.flag[2] = 0; W.flag[4] = W.flag[3]; W.flag[3] = 0; }
+        if (tid == NT - 1) { W.flag[1] = 0; W.flag[2] = 0; W.flag[4] = W.flag[3]; W.flag[3] = 0; W.flag[7] = 0; W.flag[8] = 0; W.flag[9] = 0; W.flag[10] = 0; }
         __syncthreads();
+        WGTRACE1(26);
         STAMP(4);
         WAVETRACE(t, 6);
         PMARK("A_begin");
@@ -1182,6 +1280,7 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
         if (OBST && D.map_bits) wall_rows3<NWAVES>(D, W, nagents, inv_m);
         if (obst_lines) obstacle_lines_phase3(D, W, M, AS, ko, nagents, inv_m);
         __syncthreads();
+        WGTRACE1(27);
         STAMP(5);
         WAVETRACE(t, 9);
         PMARK("B_begin");
@@ -1282,14 +1381,23 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
             PMARK("B_hp_begin");
             for (int p = tid - CAGYM_WAVE; p < lim; p += NT - CAGYM_WAVE) half_planes3<MT, LAZY_RANK && !OBST>(D, W, p, M, MP, AS, ko);
         }
+        if (OBST && ONE && o.laserscan) {
+            // the one-step launch (every step of the VecEnv path; the roll-out kernels sit at their register limit and keep the scan
+            // of their last step in the epilogue): no half-planes to build, waves 1.. would idle beside S2.  The
+            // LaserScan only reads what S1 published (pose, radius, the world's rectangles), so it runs here - it was the longest part
+            // of the epilogue (wave 0 joins behind S2); a world restarted by S2 is scanned again in the epilogue (W.flag[0]).
+            laser_scan3<8>(D, W, o.laserscan, M, C.wpw, AS, inv_m, ko);
+        }
         PMARK("B_end");
         WAVETRACE(t, 10);
         __syncthreads();
+        WGTRACE1(28);
         STAMP(6);
         WAVETRACE(t, 11);
         PMARK("R_begin");
         // ---- rare: a world restarted on its next scenario -> everything derived from the old episode is rebuilt -------------
         if (AUTO_RESET && W.flag[0]) {
+            if (OBST && tid == 0) { W.flag[7] = 0; W.flag[8] = 0; W.flag[9] = 0; W.flag[10] = 0; }  // the epilogue scans again (barriers below)
             if (OBST && ko > 0) {  // the restarted worlds' rectangles (also behind the last step: the epilogue's scan uses them)
                 stage_rects3(D, W, C.wpw, C.worlds_valid);
                 __syncthreads();
@@ -1319,8 +1427,9 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
     }
     // ---- epilogue: observation of the last step on every wave, agent records -> HBM ------------------------------------------
     {
-        const CagymOut o_last = out_slice3(out, n_steps - 1, (size_t)D.N, NM, M);
-        observation_chunks3<OBST>(D, W, o_last, npairs, M, MP, K, C.wpw, C.worlds_valid, inv_m, ko);
+        CagymOut o_last = out_slice3(out, n_steps - 1, (size_t)D.N, NM, M);
+        if (OBST && ONE && !W.flag[0]) o_last.laserscan = nullptr;  // scanned beside S2 (phase B); again only after a restart
+        observation_chunks3<OBST, (ONE ? 8 : CAGYM_LASER_BATCH_ROLLOUT)>(D, W, o_last, npairs, M, MP, K, C.wpw, C.worlds_valid, inv_m, ko, AS);
         if (C.valid) {
             const Agent A = lds3_load_agent(W, threadIdx.x);  // own lane's record, written by this lane
             store_agent(D, A, (size_t)C.world * M + C.slot, true);
@@ -1362,6 +1471,8 @@ __global__ void __launch_bounds__(NT, OBST ? 2 : cagym_min_waves3(NT, MT)) k_rol
 template <int NT, int MT, int WPWT, bool AUTO_RESET, bool OBST>
 __global__ void __launch_bounds__(NT, OBST ? 2 : cagym_min_waves3(NT, MT)) k_step3(CagymDev D, const float* ext, CagymOut out, int any_rvo) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    if (OBST) { [[clang::always_inline]] run_steps3<NT, MT, WPWT, AUTO_RESET, OBST>(D, smem, ext, out, 1, any_rvo != 0); }
-    else run_steps3<NT, MT, WPWT, AUTO_RESET, OBST>(D, smem, ext, out, 1, any_rvo != 0);
+    WGTRACE(0);
+    if (OBST) { [[clang::always_inline]] run_steps3<NT, MT, WPWT, AUTO_RESET, OBST, true>(D, smem, ext, out, 1, any_rvo != 0); }
+    else run_steps3<NT, MT, WPWT, AUTO_RESET, OBST, true>(D, smem, ext, out, 1, any_rvo != 0);
+    WGTRACE(38);
 }
