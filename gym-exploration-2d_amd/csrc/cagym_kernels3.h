@@ -46,7 +46,7 @@ __device__ unsigned long long g_stamps[16];
 // into g_wgtrace (read back with cagym_debug_wgtrace()).  Same rule: the values feed no output.
 #ifdef CAGYM_WGTRACE
 #define CAGYM_WGTRACE_MAXWG 4096
-#define CAGYM_WGTRACE_W 40
+#define CAGYM_WGTRACE_W 48
 __device__ unsigned long long g_wgtrace[CAGYM_WGTRACE_MAXWG * CAGYM_WGTRACE_W];
 #define WGTRACE(slot)                                                                                       \
     do {                                                                                                    \
@@ -390,21 +390,31 @@ __device__ __forceinline__ void wall_rows3(const CagymDev& D, const Lds3& W, int
     constexpr int ROUNDS = (22 + NWAVES - 1) / NWAVES;  // <= 64 agent slots = 22 groups of 3
     const int lane = threadIdx.x & (CAGYM_WAVE - 1), wave = threadIdx.x / CAGYM_WAVE;
     const int sub = lane / 17, k = lane - sub * 17 - 8;  // lanes 51 .. 63 idle
+    // every round's raster words are requested before the first ballot (straight-line: a group beyond the last agent reads row 0 of
+    // the first world's raster and is ignored); round after round, each waited ~1 us for its two gathers
+    bool hit_row[ROUNDS];
 #pragma unroll
     for (int r = 0; r < ROUNDS; r++) {
-        const int g = wave + r * NWAVES;
-        if (g * 3 >= nagents) break;  // wave-uniform
-        const int a = g * 3 + sub;
+        const int a = (wave + r * NWAVES) * 3 + sub;
         const bool slot_ok = sub < 3 && a < nagents;
         const int ac = slot_ok ? a : 0;
         const int4 P = reinterpret_cast<const int4*>(W.wall)[ac];
         const int wl = (int)__umulhi((uint32_t)ac, inv_m);
         const uint32_t* map = D.map_bits + (size_t)W.wsc[wl] * CAGYM_MAPD * CAGYM_MAPW;
-        const bool hit_row = wall_row_hit(map, P.x, slot_ok ? P.y : 0, ((unsigned long long)(uint32_t)P.w << 32) | (uint32_t)P.z, k);
-        const unsigned long long m = __ballot(hit_row);
+        hit_row[r] = wall_row_hit(map, P.x, slot_ok ? P.y : 0, ((unsigned long long)(uint32_t)P.w << 32) | (uint32_t)P.z, k);
+    }
+#pragma unroll
+    for (int r = 0; r < ROUNDS; r++) {
+        const int a = (wave + r * NWAVES) * 3 + sub;
+        const bool slot_ok = sub < 3 && a < nagents;
+        const unsigned long long m = __ballot(hit_row[r]);
         if (slot_ok && k == -8) {
             bool hit = ((m >> (sub * 17)) & 0x1ffffull) != 0ull;
-            if (P.y & 2) hit = wall_collision(map, W.tpx[a], W.tpy[a], W.tr[a]);  // radius > 0.7 m: the whole test on this lane (rare)
+            const int4 P = reinterpret_cast<const int4*>(W.wall)[a];
+            if (P.y & 2) {  // radius > 0.7 m: the whole test on this lane (rare)
+                const int wl = (int)__umulhi((uint32_t)a, inv_m);
+                hit = wall_collision(D.map_bits + (size_t)W.wsc[wl] * CAGYM_MAPD * CAGYM_MAPW, W.tpx[a], W.tpy[a], W.tr[a]);
+            }
             W.lpk[a] = hit ? 1 : 0;
         }
     }
@@ -443,12 +453,24 @@ __device__ inline void obstacle_lines_phase3(const CagymDev& D, const Lds3& W, i
         const float radius = (float)((1 + 15e-2) * W.tr[a]), max_speed = (float)W.tpref[a];
         const float range = 5.0f * max_speed + radius, range_sq = range * range;
         const float4* rect = W.rect + (wl * Kobs + r) * 4;
+        // the four edge tests first, then ONE atomic for the rectangle's neighbours (an atomic per edge was up to four dependent LDS
+        // round trips per lane); the order of the entries does not matter: the ranking below sorts by (distance, id)
+        float dq[4];
+        int cntn = 0;
+#pragma unroll
         for (int k = 0; k < 4; k++) {
+            dq[k] = -1.0f;
             float dsq;
-            if (orca_edge_is_neighbour(rect, k, px, py, range_sq, dsq)) {
-                const int slot = __hip_atomic_fetch_add(&W.nobl[a], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (slot < ko) nbr[slot * AS + a] = make_float2(dsq, __int_as_float(4 * r + k));
-            }
+            if (orca_edge_is_neighbour(rect, k, px, py, range_sq, dsq)) { dq[k] = dsq; cntn++; }
+        }
+        if (cntn > 0) {
+            int slot = __hip_atomic_fetch_add(&W.nobl[a], cntn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (dq[k] >= 0.0f) {
+                    if (slot < ko) nbr[slot * AS + a] = make_float2(dq[k], __int_as_float(4 * r + k));
+                    slot++;
+                }
         }
     }
     __syncthreads();
@@ -788,6 +810,19 @@ __device__ __forceinline__ void ego_obs3(const CagymDev& D, const Lds3& W, float
 // LaserScanSensor.sense restricted to the samples klo..khi of beam b (every sample outside can be shown not to hit): the running
 // hit count of sensors/LaserScanSensor.py:45-58 only changes at hits, so "the last sample whose count is 1" is sample 15 when
 // exactly one hit lies in the interval, the sample before the second hit when there are more, none without a hit.
+// world_to_cell for the one-step kernel's beam samples: on its usual path (|q| < 1e6, not within 1e-7 of a cell border) the floors fit
+// an int as they are - the clamps of world_to_cell are the identity there and 8 of the ~34 fp64 operations of a sample; every other
+// input takes world_to_cell itself.  (In world_to_cell for everybody the extra branch cost the OBST roll-out kernels 8 spilled registers.)
+template <bool LEAN>
+__device__ __forceinline__ bool sample_cell(double x, double y, int& gx, int& gy) {
+    if (!LEAN) return world_to_cell(x, y, gx, gy);
+    const double qy = y * 10.0, qx = x * 10.0;
+    const bool safe = fabs(qy - rint(qy)) > 1e-7 && fabs(qx - rint(qx)) > 1e-7 && fabs(qy) < 1e6 && fabs(qx) < 1e6;
+    if (!safe) return world_to_cell(x, y, gx, gy);
+    gx = (int)floor((30 / 2.) / 0.1 - qy);
+    gy = (int)floor((30 / 2.) / 0.1 + qx);
+    return gx >= 0 && gy >= 0 && gx < CAGYM_MAPD && gy < CAGYM_MAPD;
+}
 #ifndef CAGYM_LASER_BATCH_ROLLOUT
 #define CAGYM_LASER_BATCH_ROLLOUT 4  /* gathers in flight per sampled beam in the roll-out kernels (register limit); the one-step kernel keeps 8 */
 #endif
@@ -797,6 +832,9 @@ __device__ __forceinline__ float laserscan_beam_range(const uint32_t* map, doubl
     int egx, egy;
     const bool ego_in = world_to_cell(px, py, egx, egy);
     const double rr = radius / 0.1, r2 = rr * rr;
+    // the own-disc mask (dx^2 + dy^2 < r2 on cell offsets) on integers: for an integer d, d < r2 <=> d <= ceil(r2) - 1 (fp64 is half rate
+    // on this part and the sixteen samples of a beam are fp64 from end to end: every operation taken out of them shows)
+    const int disc_lim = r2 < 1e9 ? (int)ceil(r2) - 1 : 0x7fffffff;
     const double astep = (kPi - (-kPi)) / 15.0, rstep = 2 * kPi / 16;
     const double ang0 = b == 15 ? kPi : (double)b * astep + (-kPi);
     double sa, ca;
@@ -818,10 +856,10 @@ __device__ __forceinline__ float laserscan_beam_range(const uint32_t* map, doubl
             if (in) {
                 const double rg = 0.0 + (double)k * rstep;
                 const double x = px + rg * ca, y = py + rg * sa;
-                in = world_to_cell(x, y, gx, gy);
+                in = sample_cell<(BATCH >= 8)>(x, y, gx, gy);
                 if (in && ego_in) {
-                    const double dx = (double)(gy - egy), dy = (double)(gx - egx);
-                    in = !(dx * dx + dy * dy < r2);
+                    const int dx = gy - egy, dy = gx - egx;  // both cells lie in the 300 x 300 map: no overflow
+                    in = !(dx * dx + dy * dy <= disc_lim);
                 }
             }
             valid |= in ? (1u << q) : 0u;
@@ -1123,6 +1161,9 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
             int dbg[3] = {0, 0, 0};
 #endif
             PMARK("C_lp_loop");
+            // (cfg4: nearly every ego among rectangles is busy - median 35 of a workgroup's 36 RVO agents - so 70 % of the workgroups run
+            // a second round of groups for a handful of egos.  Groups of FOUR lanes with four half-planes per lane - one round for up
+            // to 64 egos, orca_lp_group_n<4, 4> - were measured slower: this phase 8.6 -> 9.4 us, tools/cfg4_timeline.py.)
             for (int base = 0; base < cnt; base += NG) {
                 const int idx = base + g;
                 if (idx < cnt) {
@@ -1277,7 +1318,9 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
         WAVETRACE(t, 8);
         const bool obst_lines = OBST && ko > 0 && any_rvo && t + 1 < n_steps;
         if (OBST && (D.map_bits || obst_lines)) __syncthreads();
+        WGTRACE1(40);
         if (OBST && D.map_bits) wall_rows3<NWAVES>(D, W, nagents, inv_m);
+        WGTRACE1(41);
         if (obst_lines) obstacle_lines_phase3(D, W, M, AS, ko, nagents, inv_m);
         __syncthreads();
         WGTRACE1(27);
@@ -1472,6 +1515,9 @@ template <int NT, int MT, int WPWT, bool AUTO_RESET, bool OBST>
 __global__ void __launch_bounds__(NT, OBST ? 2 : cagym_min_waves3(NT, MT)) k_step3(CagymDev D, const float* ext, CagymOut out, int any_rvo) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     WGTRACE(0);
+#ifdef CAGYM_WGTRACE
+    if (threadIdx.x == 0 && blockIdx.x < CAGYM_WGTRACE_MAXWG) g_wgtrace[blockIdx.x * CAGYM_WGTRACE_W + 39] = 0;
+#endif
     if (OBST) { [[clang::always_inline]] run_steps3<NT, MT, WPWT, AUTO_RESET, OBST, true>(D, smem, ext, out, 1, any_rvo != 0); }
     else run_steps3<NT, MT, WPWT, AUTO_RESET, OBST, true>(D, smem, ext, out, 1, any_rvo != 0);
     WGTRACE(38);

@@ -29,7 +29,7 @@ for _ in range(60):
     ga3c.act(ext)
     env.step(ext, auto_reset=True)
 torch.cuda.synchronize()
-W = 40
+W = 48
 name = env.kernel_name(rollout=False, auto_reset=True)
 wpw = 4 if "10, 4" in name else 5
 n_wg = min((N + wpw - 1) // wpw, 4096)
@@ -38,10 +38,10 @@ pts = [(0, "entry"), (20, "agent records HBM -> LDS, barrier"), (21, "rectangles
        (35, "obstacle lines 3: rank + half-plane per (ego, candidate)"), (36, "obstacle lines 4: coverage bits per (ego, candidate, earlier line)"),
        (22, "obstacle lines 5: per-ego walk, compaction (one wave)"),
        (23, "pair distances, barrier"), (1, "agent half-planes, barrier (prologue ends)"), (24, "C: busy list + linear programs"),
-       (25, "D: S1 on wave 0 (no rows: first step), barrier"), (26, "publish, barrier"), (27, "A: pair distances, wall test, barrier"),
+       (25, "D: S1 on wave 0 (no rows: first step), barrier"), (26, "publish, barrier"), (40, "A: wall prep (wave 0), pair distances, barrier"), (41, "A: wall rows (thread 0's wave)"), (27, "A: barrier"),
        (28, "B: S2 (+ auto-reset), barrier"), (2, "reset rebuild (rare)"), (38, "epilogue: OAS rows + laser scans + state -> HBM")]
 acc = {k: [] for k, _ in pts[1:]}
-spans, own, entries, las, ntodo = [], [], [], [], []
+spans, own, entries, las, ntodo, busy = [], [], [], [], [], []
 for rep in range(20):
     ga3c.act(ext)
     torch.cuda.synchronize()
@@ -59,6 +59,7 @@ for rep in range(20):
     entries.append(np.sort((T[:, 0] - t0) * 0.01))
     las.append(np.stack([(T[:, 30] - T[:, 29]) * 0.01, (T[:, 31] - T[:, 30]) * 0.01, T[:, 32].astype(np.float64)], 1))
     ntodo.append(T[:, 37].copy())
+    busy.append((T[:, 39] >> 8).copy())
 own = np.concatenate(own)
 print("%s, %d worlds = %d workgroups; 20 launches; kernel span (first entry -> last exit) median %.1f us" % (name, N, n_wg, np.median(spans)))
 print("a workgroup's own duration: median %.1f  p10 %.1f  p90 %.1f  max %.1f us" % (np.median(own), np.percentile(own, 10), np.percentile(own, 90), own.max()))
@@ -76,3 +77,5 @@ print("LaserScan, wave 1's share: the slab-test passes it claimed (of %d, 64 bea
 nt = np.concatenate(ntodo)
 print("obstacle lines: (ego, candidate) work items per workgroup median %d p90 %d; x longest candidate list = coverage items" % (np.median(nt & 0xffff), np.percentile(nt & 0xffff, 90)))
 print("                longest candidate list median %d p90 %d" % (np.median(nt // 65536), np.percentile(nt // 65536, 90)))
+bz = np.concatenate(busy)
+print("busy egos (LP groups) per workgroup: median %d p90 %d max %d; workgroups with more than 32 (a second round of LP groups): %.1f %%" % (np.median(bz), np.percentile(bz, 90), bz.max(), 100.0 * (bz > 32).mean()))

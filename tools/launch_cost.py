@@ -78,7 +78,7 @@ def part_b():
     for _ in range(4):
         env.rollout(64, out=traj)
     torch.cuda.synchronize()
-    W = 40
+    W = 48
     n_wg = (N + 3) // 4 if M == 10 and (N + 3) // 4 <= 5 * 256 else (N + 4) // 5 if M == 10 else 0
     if not n_wg:
         print("Part B handles M = 10 only")

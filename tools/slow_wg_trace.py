@@ -20,7 +20,7 @@ env.reset()
 traj = env.alloc_rollout(64)
 for _ in range(6):
     env.rollout(64, out=traj)
-n_wg, W, P = 1024, 40, 16
+n_wg, W, P = 1024, 48, 16
 names = ["step top", "busy list built", "own LP groups done", "wave 0: all LP waves done", "S1 done (w0) / rows done (others)", "after barrier X",
          "after publish + barrier Y", "last wave: ego frame + LP inputs done", "pair distances done", "after barrier A",
          "S2 done (w0) / half-planes done (others)", "after barrier B", "step end", "LP: lines loaded, start point", "LP: linearProgram2 done", "S1: action chosen (orca_post)"]
