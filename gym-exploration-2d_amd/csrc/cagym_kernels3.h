@@ -811,7 +811,7 @@ __device__ __forceinline__ void ego_obs3(const CagymDev& D, const Lds3& W, float
 // hit count of sensors/LaserScanSensor.py:45-58 only changes at hits, so "the last sample whose count is 1" is sample 15 when
 // exactly one hit lies in the interval, the sample before the second hit when there are more, none without a hit.
 // world_to_cell for the one-step kernel's beam samples: on its usual path (|q| < 1e6, not within 1e-7 of a cell border) the floors fit
-// an int as they are - the clamps of world_to_cell are the identity there and 8 of the ~34 fp64 operations of a sample; every other
+// an int as they are - the clamps of world_to_cell are the identity there (12 of a sample's ~60 instructions); every other
 // input takes world_to_cell itself.  (In world_to_cell for everybody the extra branch cost the OBST roll-out kernels 8 spilled registers.)
 template <bool LEAN>
 __device__ __forceinline__ bool sample_cell(double x, double y, int& gx, int& gy) {
@@ -832,8 +832,8 @@ __device__ __forceinline__ float laserscan_beam_range(const uint32_t* map, doubl
     int egx, egy;
     const bool ego_in = world_to_cell(px, py, egx, egy);
     const double rr = radius / 0.1, r2 = rr * rr;
-    // the own-disc mask (dx^2 + dy^2 < r2 on cell offsets) on integers: for an integer d, d < r2 <=> d <= ceil(r2) - 1 (fp64 is half rate
-    // on this part and the sixteen samples of a beam are fp64 from end to end: every operation taken out of them shows)
+    // the own-disc mask (dx^2 + dy^2 < r2 on cell offsets) on integers: for an integer d, d < r2 <=> d <= ceil(r2) - 1 (the sixteen
+    // samples of a beam are ~1000 instructions per round of 64 beams, conversions and fp64 from end to end: what is taken out shows)
     const int disc_lim = r2 < 1e9 ? (int)ceil(r2) - 1 : 0x7fffffff;
     const double astep = (kPi - (-kPi)) / 15.0, rstep = 2 * kPi / 16;
     const double ang0 = b == 15 ? kPi : (double)b * astep + (-kPi);
