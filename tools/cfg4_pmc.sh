@@ -9,4 +9,3 @@ python tools/pmc_summary.py $O/p1 k_step3 > $O/p1.txt
 rocprofv3 --kernel-trace --output-format csv --pmc SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d $O/p2 -o run -- $CMD > $O/p2.log 2>&1 && python tools/pmc_summary.py $O/p2 k_step3 > $O/p2.txt
 rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_VALU_TRANS SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_MISC GRBM_GUI_ACTIVE -d $O/p3 -o run -- $CMD > $O/p3.log 2>&1 && python tools/pmc_summary.py $O/p3 k_step3 > $O/p3.txt
 cat $O/p1.txt $O/p2.txt $O/p3.txt 2>/dev/null
-tail -3 $O/p2.log $O/p3.log

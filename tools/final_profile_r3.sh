@@ -42,6 +42,8 @@ python bench.py --config cfg5 --steps 200 --warmup 50 > $O/bench_cfg5.json 2> $O
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_cfg4 -o run -- python3 bench.py --config cfg4 --steps 200 --warmup 50 --repeats 5 --no-cpu-baseline > $O/bench_cfg4_under_rocprof.json 2>/dev/null
 tools/cfg5_profile.sh $O/cfg5_prof > $O/cfg5_prof.log 2>&1
 python tools/cfg4_outcomes.py > $O/cfg4_outcomes.txt 2>&1
+python tools/cfg4_timeline.py 2>&1 | grep -v amdgpu.ids > $O/cfg4_timeline.txt
+tools/cfg4_pmc.sh $O/cfg4_pmc 2>&1 | grep -v amdgpu.ids > $O/cfg4_pmc.txt
 echo rows done
 CAGYM_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 20 --warmup 5 --no-cpu-baseline > $O/rehearsal_2ranks_gloo_driver_cmd.json 2> $O/rehearsal_2ranks_gloo_driver_cmd.err
 CAGYM_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 512 --warmup 64 --roll 64 --repeats 5 --no-cpu-baseline > $O/rehearsal_2ranks_gloo.json 2> $O/rehearsal_2ranks_gloo.err

@@ -7,7 +7,7 @@ shutil.copy(O + "stats/run_kernel_stats.csv", P + "bench_4096x10_rvo_kernel_stat
 shutil.copy(O + "stats20/run_kernel_stats.csv", P + "bench_driver_cmd_20steps_kernel_stats.csv")
 shutil.copy(O + "stats_cfg4/run_kernel_stats.csv", P + "bench_cfg4_kernel_stats.csv")
 for a in ("bench_default.json", "bench_driver_cmd.json", "bench_under_rocprof.json", "bench20_under_rocprof.json", "bench_cfg4.json",
-          "bench_cfg5.json", "wave_trace_4096.txt", "launch_cost.txt", "slow_workgroup_wave_trace.txt", "smoke.log", "cfg4_outcomes.txt", "valu_breakdown.txt"):
+          "bench_cfg5.json", "wave_trace_4096.txt", "launch_cost.txt", "slow_workgroup_wave_trace.txt", "smoke.log", "cfg4_outcomes.txt", "valu_breakdown.txt", "cfg4_timeline.txt", "cfg4_pmc.txt"):
     shutil.copy(O + a, P + a)
 # the 2-rank rehearsal prints gloo warnings on stderr only; keep the JSON line alone
 open(P + "rehearsal_2ranks_one_gpu_gloo.json", "w").write(
