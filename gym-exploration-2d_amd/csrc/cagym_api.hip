@@ -261,7 +261,7 @@ int cagym_create(const cagym_config* cfg, void** env_out) {
             int cus = 256;
             if (hipGetDeviceProperties(&prop, e->cfg.device) == hipSuccess && prop.multiProcessorCount > 0)
                 cus = prop.multiProcessorCount;
-            e->wpw10 = (e->cfg.n_worlds + 3) / 4 <= 4 * cus ? 4 : 5;  // 4 workgroups per CU fit (128 VGPRs; 30.4 KB of LDS with 4 worlds, 37.7 KB with 5)
+            e->wpw10 = (e->cfg.n_worlds + 3) / 4 <= 4 * cus ? 4 : 5;  // 4 workgroups per CU fit (128 VGPRs; 30.9 KB of LDS with 4 worlds, 37.7 KB with 5)
             if (has_map(e) && e->wpw10 == 5) {
                 // worlds with rectangles (OBST instantiation, 135 VGPRs: at most 3 workgroups per CU): 4 worlds per workgroup when their
                 // smaller LDS footprint buys a workgroup per CU (cfg4: 53.4 KB -> 3 per CU, 65.9 KB with 5 worlds -> 2;
