@@ -35,6 +35,7 @@ struct Env {
     IgDev G{};
     uint32_t* ig_any = nullptr;
     int32_t* gen_failed = nullptr;  // device word: agents whose rejection loop hit max_tries (cagym_generate_scenarios)
+    int32_t* ga3c_ctr = nullptr;    // device words of cagym_ga3c_act's list (k_ga3c_select): ticket, list start, list length
     bool ig_ready = false;
     int any_rvo = 1;
     int obst_rvo = 0;    // RVO agents in worlds with rectangles: the kernels build obstacle half-planes (OBST instantiations)
@@ -240,6 +241,7 @@ int cagym_create(const cagym_config* cfg, void** env_out) {
     A(dalloc(e, &D.n_agents, N)); A(dalloc(e, &D.episode, N)); A(dalloc(e, &D.ep_len, N));
     A(dalloc(e, &D.ep_return, N)); A(dalloc(e, &D.stat_return, N)); A(dalloc(e, &D.stat_episodes, N));
     A(dalloc(e, &D.stat_steps, N)); A(dalloc(e, &D.stat_outcomes, N * 3));
+    A(dalloc(e, &e->ga3c_ctr, 4));  // at creation: cagym_ga3c_act may run inside a stream capture (no allocation there)
 #undef A
     e->err.clear();
     size_t lds = cagym_lds_bytes((int)M);
@@ -638,12 +640,12 @@ int cagym_pack_episode_stats(void* env, int32_t* records, void* stream) {
     return CAGYM_OK;
 }
 
-static void launch_ga3c_state(Env* e, int max_observed, const int32_t* agent_idx, long long rows, const int32_t* B_dev, float* state,
+static void launch_ga3c_state(Env* e, int max_observed, const int32_t* agent_idx, long long rows, uint32_t* ctr, float* state,
                               hipStream_t st) {
     if (e->cfg.max_agents <= 16)
-        hipLaunchKernelGGL(k_ga3c_state<16>, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, st, e->D, max_observed, agent_idx, (int)rows, B_dev, state);
+        hipLaunchKernelGGL(k_ga3c_state<16>, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, st, e->D, max_observed, agent_idx, (int)rows, ctr, state);
     else
-        hipLaunchKernelGGL(k_ga3c_state<32>, dim3((unsigned)((rows + 7) / 8)), dim3(256), 0, st, e->D, max_observed, agent_idx, (int)rows, B_dev, state);
+        hipLaunchKernelGGL(k_ga3c_state<32>, dim3((unsigned)((rows + 7) / 8)), dim3(256), 0, st, e->D, max_observed, agent_idx, (int)rows, ctr, state);
 }
 
 int cagym_ga3c_state(void* env, int max_observed, float* state, void* stream) {
@@ -671,15 +673,15 @@ int cagym_ga3c_act(void* env, const float* weights, int max_observed, void* work
     DEVGUARD(e);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const size_t total = (size_t)e->cfg.n_worlds * e->cfg.max_agents;
-    int32_t* count = reinterpret_cast<int32_t*>(work);
     int32_t* idx = reinterpret_cast<int32_t*>(reinterpret_cast<unsigned char*>(work) + 256);
     float* state = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(work) + 256 + a16(total * sizeof(int32_t)));
-    HIPCHK(e, hipMemsetAsync(count, 0, sizeof(int32_t), st));
-    hipLaunchKernelGGL(k_ga3c_select, dim3((unsigned)((total + 1023) / 1024)), dim3(1024), 0, st, e->D, idx, count);
-    // the list length stays on the device: both kernels are launched for the worst case and leave beyond *count
-    launch_ga3c_state(e, max_observed, idx, (long long)total, count, state, st);
-    hipLaunchKernelGGL(k_ga3c_forward_mfma, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, st, weights, state, idx, 0, count, e->D.pref,
-                       ext_actions, (int32_t*)nullptr, (float*)nullptr);
+    // no memset in front of the chain: the handle's ticket words carry the list from call to call (k_ga3c_select)
+    uint32_t* ctr = reinterpret_cast<uint32_t*>(e->ga3c_ctr);
+    hipLaunchKernelGGL(k_ga3c_select, dim3((unsigned)((total + 1023) / 1024)), dim3(1024), 0, st, e->D, idx, ctr);
+    // the list length stays on the device: both kernels are launched for the worst case and leave beyond it
+    launch_ga3c_state(e, max_observed, idx, (long long)total, ctr, state, st);
+    hipLaunchKernelGGL(k_ga3c_forward_mfma, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, st, weights, state, idx, 0, e->ga3c_ctr + 2, e->D.pref,
+                       ext_actions, (int32_t*)nullptr, (float*)nullptr, ctr);
     HIPCHK(e, hipGetLastError());
     return CAGYM_OK;
 }
@@ -722,7 +724,7 @@ int cagym_ga3c_forward(void* env, const float* weights, const float* state, cons
     const bool use_valu = which && !strcmp(which, "valu");
     if (!use_valu)  // default: the matrix-core kernel (CAGYM_GA3C=valu selects round 1's vector kernel, for A/B)
         hipLaunchKernelGGL(k_ga3c_forward_mfma, dim3((unsigned)((B + 31) / 32)), dim3(256), 0, st, weights, state, agent_idx, B,
-                           (const int32_t*)nullptr, e->D.pref, ext_actions, action_index, probs);
+                           (const int32_t*)nullptr, e->D.pref, ext_actions, action_index, probs, (uint32_t*)nullptr);
     else if (B <= 16 * 1024)
         hipLaunchKernelGGL(k_ga3c_forward<16>, dim3((unsigned)((B + 15) / 16)), dim3(256), 0, st, weights, state, agent_idx, B,
                            e->D.pref, ext_actions, action_index, probs);

@@ -199,6 +199,18 @@ __global__ void __launch_bounds__(256) k_ga3c_forward(const float* __restrict__ 
 // Layouts (MI355X guide): A[i = l & 31][k = l >> 5], B[k = l >> 5][j = l & 31], D reg r of lane l = row (r & 3) + 8 (r >> 2) +
 // 4 (l >> 5), column l & 31.
 typedef float ga_f32x16 __attribute__((ext_vector_type(16)));
+// Diagnostic build only (-DCAGYM_STAMPS -DGA_STAMPS, tools/ga3c_phases.py): thread 0 of every workgroup adds the s_memtime
+// ticks of the forward kernel's phases to g_stamps[0..5] and counts itself in g_stamps[15]
+#if defined(CAGYM_STAMPS) && defined(GA_STAMPS)
+#define GASTAMP_BEGIN() unsigned long long ga_prev = __builtin_amdgcn_s_memtime()
+#define GASTAMP(i) do { if (threadIdx.x == 0) { unsigned long long _t = __builtin_amdgcn_s_memtime(); atomicAdd(&g_stamps[i], _t - ga_prev); ga_prev = _t; } } while (0)
+#else
+#define GASTAMP_BEGIN() do { } while (0)
+#define GASTAMP(i) do { } while (0)
+#endif
+#ifndef GA_DENSE_U
+#define GA_DENSE_U 8  /* k-pairs per software-pipeline stage of the dense layers */
+#endif
 
 // One dense layer's accumulation for this wave's two tiles: acc += in[32 agents x K] * Wt[K x columns c0 / c1].  The weights come
 // from L2 (every workgroup reads the same 0.7 MB), so the loop is software-pipelined by hand over two named register sets
@@ -278,9 +290,12 @@ __device__ __forceinline__ void ga_store_tile_relu(float* act, int neuron, const
 __global__ void __launch_bounds__(256, 2) k_ga3c_forward_mfma(const float* __restrict__ Wb, const float* __restrict__ state,
                                                            const int32_t* __restrict__ agent_idx, int B_host,
                                                            const int32_t* __restrict__ B_dev, const double* __restrict__ pref,
-                                                           float* ext_actions, int32_t* action_index, float* probs) {
+                                                           float* ext_actions, int32_t* action_index, float* probs, uint32_t* list_ctr) {
     const int B = B_dev ? *B_dev : B_host;  // device-side count (cagym_ga3c_act): the grid covers the worst case
+    // the last kernel of cagym_ga3c_act's chain starts the next list where this one ended (k_ga3c_select; nobody reads these two words now)
+    if (list_ctr && blockIdx.x == 0 && threadIdx.x == 0) list_ctr[1] = list_ctr[0];
     if ((int)blockIdx.x * 32 >= B) return;
+    GASTAMP_BEGIN();
     constexpr int AG = 32, HB = (4 + GA_H + 1) * AG;
     // One 40.6 KB LDS block (3 workgroups per CU):
     //   hb0 | hb1: [4 host features | 64 hidden | one zero row][agent], double-buffered over the LSTM steps (one barrier per step);
@@ -339,6 +354,7 @@ __global__ void __launch_bounds__(256, 2) k_ga3c_forward_mfma(const float* __res
         wl1[p] = k < 7 + GA_H ? Wb[GA_OFF_WL + (size_t)k * GA_W + lc1] : 0.f;
     }
     __syncthreads();
+    GASTAMP(0);
     int tmax = 0;
     for (int g = 0; g < AG; g++) tmax = nseq[g] > tmax ? nseq[g] : tmax;
     uint32_t live_until = 0;  // sequence lengths (<= 10) of this lane's eight agents, 4 bits each
@@ -385,24 +401,30 @@ __global__ void __launch_bounds__(256, 2) k_ga3c_forward_mfma(const float* __res
         __syncthreads();  // the other buffer is complete; everyone has finished reading this one
     }
     // ---- layer1: concat[host(4), h(64)] -> 256, ReLU: the final h buffer as it stands -------------------------------------
+#ifdef GA_STAGGER
+    for (int i = 0; i < (int)(blockIdx.x & 7); i++) __builtin_amdgcn_s_sleep(GA_STAGGER);
+#endif
+    GASTAMP(1);
     const float* hfin = hb;
     const int c0 = 64 * wave + j, c1 = 64 * wave + 32 + j;
     {
         ga_f32x16 a0 = ga_splat(Wb[GA_OFF_B1 + c0]), a1 = ga_splat(Wb[GA_OFF_B1 + c1]);
-        ga_mfma_layer<8, 2>(hfin, 4 + GA_H, Wb + GA_OFF_W1, GA_W, c0, c1, true, a0, a1);
+        ga_mfma_layer<GA_DENSE_U, 2>(hfin, 4 + GA_H, Wb + GA_OFF_W1, GA_W, c0, c1, true, a0, a1);
         ga_store_tile_relu(za, c0, a0);
         ga_store_tile_relu(za, c1, a1);
     }
     __syncthreads();
+    GASTAMP(2);
 #pragma unroll 1
     for (int layer = 0; layer < 2; layer++) {
         const int ob = layer == 0 ? GA_OFF_B2 : GA_OFF_B3;
         ga_f32x16 a0 = ga_splat(Wb[ob + c0]), a1 = ga_splat(Wb[ob + c1]);
-        ga_mfma_layer<8, 2>(za, GA_W, Wb + (layer == 0 ? GA_OFF_W2 : GA_OFF_W3), GA_W, c0, c1, true, a0, a1);
+        ga_mfma_layer<GA_DENSE_U, 2>(za, GA_W, Wb + (layer == 0 ? GA_OFF_W2 : GA_OFF_W3), GA_W, c0, c1, true, a0, a1);
         __syncthreads();  // in place: every wave has read the whole input
         ga_store_tile_relu(za, c0, a0);
         ga_store_tile_relu(za, c1, a1);
         __syncthreads();
+        GASTAMP(3 + layer);
     }
     // ---- logits_p 256 -> 11: each wave sums its quarter of k on one tile (columns >= 11 are zero weights) ---------------------
     {
@@ -440,4 +462,8 @@ __global__ void __launch_bounds__(256, 2) k_ga3c_forward_mfma(const float* __res
             ext_actions[2 * (size_t)a + 1] = (float)a1;
         }
     }
+    GASTAMP(5);
+#if defined(CAGYM_STAMPS) && defined(GA_STAMPS)
+    if (threadIdx.x == 0) atomicAdd(&g_stamps[15], 1ull);
+#endif
 }

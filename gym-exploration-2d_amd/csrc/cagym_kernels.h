@@ -587,17 +587,10 @@ __global__ void __launch_bounds__(256) k_rasterize(const double* obst, const int
 // inactive slots.  agent_idx == null: every agent slot of the handle; else the B (or *B_dev) listed agents only - the
 // reference builds the vector for the GA3C agent alone (find_next_action is per agent).
 #ifndef CAGYM_K3_UNIT  // the generation-3 units include this header for its device functions only
+// the state row of one agent on the LPA lanes of group `al` (every thread of the block calls it: one barrier inside)
 template <int LPA>
-__global__ void __launch_bounds__(256) k_ga3c_state(CagymDev D, int max_observed, const int32_t* __restrict__ agent_idx, int B,
-                                                    const int32_t* __restrict__ B_dev, float* out) {
-    constexpr int APB = 256 / LPA;
-    __shared__ double sk1[APB][LPA], sk2[APB][LPA];
-    const int al = threadIdx.x / LPA, j = threadIdx.x % LPA;
-    const long long total = agent_idx ? (long long)(B_dev ? *B_dev : B) : (long long)D.N * D.M;
-    if ((long long)blockIdx.x * APB >= total) return;  // uniform: the whole block is beyond the list
-    const long long q = (long long)blockIdx.x * APB + al;
-    const bool have = q < total;
-    const size_t a = have ? (agent_idx ? (size_t)agent_idx[q] : (size_t)q) : 0;
+__device__ __forceinline__ void ga3c_state_row(const CagymDev& D, int max_observed, bool have, size_t a, int al, int j,
+                                               double (*sk1)[LPA], double (*sk2)[LPA], float* out) {
     const int world = (int)(a / D.M), i = (int)(a - (size_t)world * D.M);
     float* o = out + a * 76;
     if (have)
@@ -657,12 +650,34 @@ __global__ void __launch_bounds__(256) k_ga3c_state(CagymDev D, int max_observed
         o[5] = (float)ri;
     }
 }
+
+template <int LPA>
+__global__ void __launch_bounds__(256) k_ga3c_state(CagymDev D, int max_observed, const int32_t* __restrict__ agent_idx, int B,
+                                                    uint32_t* ctr, float* out) {
+    constexpr int APB = 256 / LPA;
+    __shared__ double sk1[APB][LPA], sk2[APB][LPA];
+    const int al = threadIdx.x / LPA, j = threadIdx.x % LPA;
+    // ctr (cagym_ga3c_act): the list k_ga3c_select just built holds ctr[0] - ctr[1] agents; word 2 passes that on to the forward kernel
+    const uint32_t listed = ctr ? ctr[0] - ctr[1] : 0u;
+    if (ctr && blockIdx.x == 0 && threadIdx.x == 0) ctr[2] = listed;
+    const long long total = agent_idx ? (long long)(ctr ? (int)listed : B) : (long long)D.N * D.M;
+    if ((long long)blockIdx.x * APB >= total) return;  // uniform: the whole block is beyond the list
+    const long long q = (long long)blockIdx.x * APB + al;
+    const bool have = q < total;
+    const size_t a = have ? (agent_idx ? (size_t)agent_idx[q] : (size_t)q) : 0;
+    ga3c_state_row<LPA>(D, max_observed, have, a, al, j, sk1, sk2, out);
+}
+
 #endif
 
 // indices (world * M + slot) of the active agents whose policy id is CAGYM_POL_GA3C, compacted on the device (order within
-// the list is not fixed: every consumer treats the listed agents independently).  *count must be zero on entry.
+// the list is not fixed: every consumer treats the listed agents independently).  The list needs no reset from the host
+// (round 3; a memset in front of every call was 4.9 us of cfg4's step): ctr[0] is a ticket counter that only ever grows
+// (unsigned, wraps), ctr[1] its value when this list began; a place in the list is ticket - ctr[1].  k_ga3c_state turns the
+// difference into the list length (ctr[2]) and the forward kernel - the last reader - starts the next list (ctr[1] = ctr[0]).
+// The words are the handle's, zero at creation; the chain replays from a captured graph as it is.
 #ifndef CAGYM_K3_UNIT  // the generation-3 units include this header for its device functions only
-__global__ void __launch_bounds__(1024) k_ga3c_select(CagymDev D, int32_t* idx, int32_t* count) {
+__global__ void __launch_bounds__(1024) k_ga3c_select(CagymDev D, int32_t* idx, uint32_t* ctr) {
     // one returning atomic per 1024-thread block (all of them hit one L2 address: per-wave atomics took 16 us for 81 920 slots)
     __shared__ int wave_cnt[16], wave_base[16];
     const size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -679,7 +694,7 @@ __global__ void __launch_bounds__(1024) k_ga3c_select(CagymDev D, int32_t* idx, 
     if (threadIdx.x == 0) {
         int tot = 0;
         for (int w = 0; w < 16; w++) { wave_base[w] = tot; tot += wave_cnt[w]; }
-        const int base = tot ? atomicAdd(count, tot) : 0;
+        const int base = tot ? (int)(atomicAdd(&ctr[0], (uint32_t)tot) - ctr[1]) : 0;
         for (int w = 0; w < 16; w++) wave_base[w] += base;
     }
     __syncthreads();

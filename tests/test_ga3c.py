@@ -186,3 +186,42 @@ def test_fused_act_selects_only_ga3c_agents():
         env.step(extf, auto_reset=True)
     assert int(env.state()["episode"].max()) >= 1  # restarts happened
     env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M", [10, 20])
+def test_fused_act_many_blocks_many_rounds_and_graph_replay(M):
+    """cagym_ga3c_act with every slot a GA3C agent (several selection blocks racing for their places in the list) and the chain
+    replayed from a captured HIP graph: the list's ticket words carry over from call to call on the device, there is no
+    host-side reset (round 3 removed the memset in front of the chain)."""
+    import torch
+    B = importlib.import_module("gym-exploration-2d_amd.batched_env").BatchedCollisionAvoidanceEnv
+    GA3C = importlib.import_module("gym-exploration-2d_amd.ga3c").GA3CCADRLPolicy
+    N, S = 333, 400
+    rng = np.random.default_rng(11)
+    n_agents = rng.integers(2, M + 1, S).astype(np.int32)
+    env = B(N, M, n_scenarios=S, game_over_mode="all")
+    env.set_scenarios(scen.random_worlds_fast(S, M, seed=4), scen.POLICY_GA3C, scen.DYN_UNICYCLE, n_agents=n_agents)
+    env.reset()
+    policy = GA3C(env)
+    ext_g = torch.full((N, M, 2), 7.0, dtype=torch.float32, device=env.device)
+    policy.act(ext_g, fused=True)  # allocates the workspace outside the capture
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        policy.act(ext_g, fused=True)
+    for t in range(12):
+        ext3 = torch.full((N, M, 2), 7.0, dtype=torch.float32, device=env.device)
+        ext_g.fill_(7.0)
+        g.replay()
+        policy.act(ext3, fused=False)
+        if t % 3 == 1:  # eager calls between the replays share the same ticket words
+            exte = torch.full((N, M, 2), 7.0, dtype=torch.float32, device=env.device)
+            policy.act(exte, fused=True)
+            assert torch.equal(exte, ext3), t
+        torch.cuda.synchronize()
+        assert torch.equal(ext_g, ext3), t
+        st = env.state()["status"].cpu().numpy().reshape(N, M)
+        assert np.array_equal((ext_g.cpu().numpy() != 7.0).any(axis=2), (st & 64) != 0), t
+        env.step(ext3, auto_reset=True)
+    env.close()
