@@ -221,18 +221,31 @@ template <int U, int TILES>
 struct GaOperands {
     float a[U], b0[U], b1[U];
 };
+// K (even: 68, 256, 64) is a template argument.  Stages of U k-pairs (rows 2 kp, 2 kp + 1) in a rolled loop over PAIRS of stages;
+// the k-pairs beyond the last full pair of stages (layer1: 2 of 34) follow as straight-line code, so that no stage is padded:
+// the row of every load is UNIFORM - a weight address is a scalar row pointer + the lane's fixed offset (half * ldw + column),
+// an A operand a fixed LDS offset from the stage's base - no vector arithmetic per load, no select on the A operand.
+// (Round 2 clamped the row per lane: ~6 vector instructions per load, 100+ per stage, all of them issued BEFORE the stage's
+// matrix instructions because of the scheduling fences: a dense stage took 1 690 cycles for 1 024 cycles of matrix work,
+// tools/ga3c_phases.py.)
 template <int U, int TILES>
-__device__ __forceinline__ void ga_fetch(GaOperands<U, TILES>& o, const float* __restrict__ in, int K, const float* __restrict__ Wt, int ldw,
-                                         int c0, int c1, int blk) {
-    const int lane = threadIdx.x & 63, half = lane >> 5, j = lane & 31;
+__device__ __forceinline__ void ga_fetch(GaOperands<U, TILES>& o, const float* __restrict__ ain_blk, const float* __restrict__ wrow_blk, int ldw,
+                                         uint32_t boff0, uint32_t boff1) {
 #pragma unroll
     for (int i = 0; i < U; i++) {
-        const int k = 2 * (blk * U + i) + half;
-        const int kc = k < K ? k : K - 1;
-        const float av = in[kc * 32 + j];
-        o.a[i] = k < K ? av : 0.f;
-        o.b0[i] = Wt[(size_t)kc * ldw + c0];
-        if (TILES == 2) o.b1[i] = Wt[(size_t)kc * ldw + c1];
+        const float* row = wrow_blk + (size_t)(2 * i) * ldw;
+#ifdef GA_DIAG_NOA  // diagnostic builds (tools/ga3c_phases.py): the layer without its LDS reads / without its weight loads
+        o.a[i] = __uint_as_float(boff0 + i);
+#else
+        o.a[i] = ain_blk[i * 64];
+#endif
+#ifdef GA_DIAG_NOB
+        o.b0[i] = __uint_as_float(boff0 + 2 * i);
+        if (TILES == 2) o.b1[i] = __uint_as_float(boff1 + 2 * i);
+#else
+        o.b0[i] = row[boff0];
+        if (TILES == 2) o.b1[i] = row[boff1];
+#endif
     }
 }
 template <int U, int TILES>
@@ -243,23 +256,54 @@ __device__ __forceinline__ void ga_issue(const GaOperands<U, TILES>& o, bool use
         if (TILES == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a[i], o.b1[i], acc1, 0, 0, 0);
     }
 }
+// the order the scheduler is asked for inside one stage: the next stage's loads go between the matrix instructions of the FIRST
+// half of the stage, two k-pairs' worth per gap: they issue while the matrix core is busy, and the youngest of them is half a
+// stage old when the stage ends (the wait-count pass puts s_waitcnt vmcnt(0) at the top of a rolled loop).
 template <int U, int TILES>
-__device__ __forceinline__ void ga_mfma_layer(const float* __restrict__ in, int K, const float* __restrict__ Wt, int ldw, int c0, int c1,
+__device__ __forceinline__ void ga_stage_order() {
+#ifndef GA_NO_INTERLEAVE
+#pragma unroll
+    for (int i = 0; i < U; i++) {
+        __builtin_amdgcn_sched_group_barrier(0x008, TILES, 0);  // MFMA
+        if (i < U / 2) {
+            __builtin_amdgcn_sched_group_barrier(0x020, 2 * TILES, 0);  // VMEM read
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);          // DS read
+        }
+    }
+#endif
+}
+template <int U, int TILES, int K>
+__device__ __forceinline__ void ga_mfma_layer(const float* __restrict__ in, const float* __restrict__ Wt, int ldw, int c0, int c1,
                                               bool use0, ga_f32x16& acc0, ga_f32x16& acc1) {
-    const int kp = (K + 1) >> 1, nblk = (kp + U - 1) / U;
-    GaOperands<U, TILES> A, Bq;
-    ga_fetch<U, TILES>(A, in, K, Wt, ldw, c0, c1, 0);
+    static_assert(K % 2 == 0 && U % 2 == 0, "k-pairs, two half stages");
+    constexpr int KP = K / 2, NST = KP / (2 * U) * 2, REM = KP - NST * U;  // full stages (an even number), k-pairs behind them
+    const int lane = threadIdx.x & 63, half = lane >> 5, j = lane & 31;
+    const float* ain = in + half * 32 + j;  // A operand of k-pair kp: row 2 kp + half, agent j
+    const uint32_t boff0 = (uint32_t)(half * ldw + c0), boff1 = (uint32_t)(half * ldw + c1);
+    const size_t wst = (size_t)(2 * U) * ldw;  // weight words per stage
+    if (NST > 0) {
+        // two named register sets (no copies: the compiler would coalesce them and serialise load -> use); the fences keep a
+        // stage's loads from sinking to just before their use in the NEXT stage
+        GaOperands<U, TILES> A, Bq;
+        ga_fetch<U, TILES>(A, ain, Wt, ldw, boff0, boff1);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll 1
-    for (int blk = 0; blk < nblk; blk += 2) {  // straight-line body: blocks past the end fetch clamped rows with a zero A operand
-        // sched_barrier: the machine scheduler would otherwise sink each load to just before its use
-        ga_fetch<U, TILES>(Bq, in, K, Wt, ldw, c0, c1, blk + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        ga_issue<U, TILES>(A, use0, acc0, acc1);
-        __builtin_amdgcn_sched_barrier(0);
-        ga_fetch<U, TILES>(A, in, K, Wt, ldw, c0, c1, blk + 2);
-        __builtin_amdgcn_sched_barrier(0);
-        ga_issue<U, TILES>(Bq, use0, acc0, acc1);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int blk = 0; blk < NST; blk += 2) {
+            ga_fetch<U, TILES>(Bq, ain + (blk + 1) * U * 64, Wt + (blk + 1) * wst, ldw, boff0, boff1);
+            ga_issue<U, TILES>(A, use0, acc0, acc1);
+            ga_stage_order<U, TILES>();
+            __builtin_amdgcn_sched_barrier(0);
+            const int nb = blk + 2 < NST ? blk + 2 : NST - 1;  // behind the last stage: any valid stage again, never used
+            ga_fetch<U, TILES>(A, ain + nb * U * 64, Wt + nb * wst, ldw, boff0, boff1);
+            ga_issue<U, TILES>(Bq, use0, acc0, acc1);
+            ga_stage_order<U, TILES>();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (REM > 0) {
+        GaOperands<(REM > 0 ? REM : 1), TILES> R;
+        ga_fetch<(REM > 0 ? REM : 1), TILES>(R, ain + NST * U * 64, Wt + NST * wst, ldw, boff0, boff1);
+        ga_issue<(REM > 0 ? REM : 1), TILES>(R, use0, acc0, acc1);
     }
 }
 
@@ -313,9 +357,11 @@ __global__ void __launch_bounds__(256, 2) k_ga3c_forward_mfma(const float* __res
     static_assert(2 * HB + 10 * 7 * AG <= HB + GA_W * AG && 5 * AG * 12 <= HB, "LDS aliasing");
     const int n = threadIdx.x, tile = blockIdx.x * AG;
     const int lane = n & 63, wave = n >> 6, half = lane >> 5, j = lane & 31;
+    // list_ctr != null (cagym_ga3c_act): the state rows are stored by place in the list - row tile + g, no index look-up in front
+    const bool by_place = list_ctr != nullptr;
     for (int e = n; e < AG * 5; e += 256) {
         const int g = e / 5, f = e - g * 5;
-        const int a = tile + g < B ? agent_idx[tile + g] : -1;
+        const int a = tile + g < B ? (by_place ? tile + g : agent_idx[tile + g]) : -1;
         const float x = a >= 0 ? state[(size_t)a * 76 + 1 + f] : 0.f;
         if (f == 0) {
             int ns = (int)x;
@@ -328,7 +374,7 @@ __global__ void __launch_bounds__(256, 2) k_ga3c_forward_mfma(const float* __res
     }
     for (int e = n; e < 10 * 7 * AG; e += 256) {
         const int tc = e / AG, g = e - tc * AG, c = tc % 7;
-        const int a = tile + g < B ? agent_idx[tile + g] : -1;
+        const int a = tile + g < B ? (by_place ? tile + g : agent_idx[tile + g]) : -1;
         const float x = a >= 0 ? state[(size_t)a * 76 + 6 + tc] : 0.f;
         const float avg = c == 4 ? 0.5f : (c == 6 ? 1.0f : 0.0f);
         const float sd = (c == 0 || c == 1 || c == 5) ? 5.0f : 1.0f;
@@ -368,6 +414,9 @@ __global__ void __launch_bounds__(256, 2) k_ga3c_forward_mfma(const float* __res
         float* hnext = hb + ((t + tmax + 1) & 1) * HB;
         const float* xt = xs + t * 7 * AG;
         ga_f32x16 a0 = ga_splat(bl0), a1 = ga_splat(bl1);
+        // (Round 3 measured a split of the step - tile 0 first, i * j of the eight cells between tile 1's matrix instructions,
+        // with one and with two accumulation chains per tile -: the LSTM part 66 000 -> 73 000 cycles per workgroup both times,
+        // profiles/r3/ga3c_forward_phases.txt.  Interleaving vector work into the wave's own matrix stream does not pay here.)
 #pragma unroll
         for (int p = 0; p < LKP; p++) {
             // input row k = 2 p + half of concat[x_t (7), h (64), 0]: rows 0..6 from xs, row k >= 7 is row k - 3 of the h buffer
@@ -409,7 +458,7 @@ __global__ void __launch_bounds__(256, 2) k_ga3c_forward_mfma(const float* __res
     const int c0 = 64 * wave + j, c1 = 64 * wave + 32 + j;
     {
         ga_f32x16 a0 = ga_splat(Wb[GA_OFF_B1 + c0]), a1 = ga_splat(Wb[GA_OFF_B1 + c1]);
-        ga_mfma_layer<GA_DENSE_U, 2>(hfin, 4 + GA_H, Wb + GA_OFF_W1, GA_W, c0, c1, true, a0, a1);
+        ga_mfma_layer<GA_DENSE_U, 2, 4 + GA_H>(hfin, Wb + GA_OFF_W1, GA_W, c0, c1, true, a0, a1);
         ga_store_tile_relu(za, c0, a0);
         ga_store_tile_relu(za, c1, a1);
     }
@@ -419,7 +468,7 @@ __global__ void __launch_bounds__(256, 2) k_ga3c_forward_mfma(const float* __res
     for (int layer = 0; layer < 2; layer++) {
         const int ob = layer == 0 ? GA_OFF_B2 : GA_OFF_B3;
         ga_f32x16 a0 = ga_splat(Wb[ob + c0]), a1 = ga_splat(Wb[ob + c1]);
-        ga_mfma_layer<GA_DENSE_U, 2>(za, GA_W, Wb + (layer == 0 ? GA_OFF_W2 : GA_OFF_W3), GA_W, c0, c1, true, a0, a1);
+        ga_mfma_layer<GA_DENSE_U, 2, GA_W>(za, Wb + (layer == 0 ? GA_OFF_W2 : GA_OFF_W3), GA_W, c0, c1, true, a0, a1);
         __syncthreads();  // in place: every wave has read the whole input
         ga_store_tile_relu(za, c0, a0);
         ga_store_tile_relu(za, c1, a1);
@@ -429,7 +478,7 @@ __global__ void __launch_bounds__(256, 2) k_ga3c_forward_mfma(const float* __res
     // ---- logits_p 256 -> 11: each wave sums its quarter of k on one tile (columns >= 11 are zero weights) ---------------------
     {
         ga_f32x16 a0 = ga_splat(0.f), a1 = ga_splat(0.f);
-        ga_mfma_layer<8, 1>(za + 64 * wave * AG, 64, Wb + GA_OFF_WP + (size_t)64 * wave * 11, 11, j < 11 ? j : 0, 0, j < 11, a0, a1);
+        ga_mfma_layer<8, 1, 64>(za + 64 * wave * AG, Wb + GA_OFF_WP + (size_t)64 * __builtin_amdgcn_readfirstlane(wave) * 11, 11, j < 11 ? j : 0, 0, j < 11, a0, a1);
         if (j < 11) {
 #pragma unroll
             for (int r = 0; r < 16; r++) part[(wave * AG + (r & 3) + 8 * (r >> 2) + 4 * half) * 12 + j] = a0[r];

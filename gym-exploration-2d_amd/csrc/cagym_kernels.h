@@ -583,16 +583,16 @@ __global__ void __launch_bounds__(256) k_rasterize(const double* obst, const int
 // GA3CCADRLPolicy.agents_to_ga3c_cadrl_state (policies/GA3CCADRLPolicy.py:45-106): LPA lanes per agent (lane j <-> other agent
 // j: its distance, sort key and feature row; the rank is a count over the keys the agent's lanes left in LDS),
 // out[N,M,76] f32 = [id, n_others, dist_to_goal, heading_ego, pref_speed, radius, 10 x 7 other-agent features], rows indexed by
-// flat agent (world * M + slot); others ordered by (-round(d,2), p_orth), stable, last `max_observed` kept.  Zero rows for
+// flat agent (world * M + slot) - by place in the list for cagym_ga3c_act -; others ordered by (-round(d,2), p_orth), stable, last `max_observed` kept.  Zero rows for
 // inactive slots.  agent_idx == null: every agent slot of the handle; else the B (or *B_dev) listed agents only - the
 // reference builds the vector for the GA3C agent alone (find_next_action is per agent).
 #ifndef CAGYM_K3_UNIT  // the generation-3 units include this header for its device functions only
 // the state row of one agent on the LPA lanes of group `al` (every thread of the block calls it: one barrier inside)
 template <int LPA>
-__device__ __forceinline__ void ga3c_state_row(const CagymDev& D, int max_observed, bool have, size_t a, int al, int j,
+__device__ __forceinline__ void ga3c_state_row(const CagymDev& D, int max_observed, bool have, size_t a, size_t orow, int al, int j,
                                                double (*sk1)[LPA], double (*sk2)[LPA], float* out) {
     const int world = (int)(a / D.M), i = (int)(a - (size_t)world * D.M);
-    float* o = out + a * 76;
+    float* o = out + orow * 76;
     if (have)
         for (int c = j; c < 76; c += LPA) o[c] = 0.f;
     const int n = have ? D.n_agents[world] : 0;
@@ -665,7 +665,9 @@ __global__ void __launch_bounds__(256) k_ga3c_state(CagymDev D, int max_observed
     const long long q = (long long)blockIdx.x * APB + al;
     const bool have = q < total;
     const size_t a = have ? (agent_idx ? (size_t)agent_idx[q] : (size_t)q) : 0;
-    ga3c_state_row<LPA>(D, max_observed, have, a, al, j, sk1, sk2, out);
+    // cagym_ga3c_act's rows are stored by PLACE IN THE LIST (the forward kernel's tile of 32 agents is one contiguous 9.7 KB
+    // block and needs no index look-up in front of its loads); every other caller gets rows indexed by flat agent
+    ga3c_state_row<LPA>(D, max_observed, have, a, (ctr && have) ? (size_t)q : a, al, j, sk1, sk2, out);
 }
 
 #endif

@@ -12,7 +12,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 b = importlib.import_module("gym-exploration-2d_amd.build")
 import torch
-os.environ["CAGYM_LIB"] = b.build_variant("gastamps", ["-DCAGYM_STAMPS", "-DGA_STAMPS"] + sys.argv[1:])
+# extra compiler flags select a variant (its own library: build it in the development container, it travels), e.g. -DGA_DIAG_NOB
+TAG = "gastamps" + "".join("_" + a[2:].lower().replace("=", "") for a in sys.argv[1:])
+os.environ["CAGYM_LIB"] = b.build_variant(TAG, ["-DCAGYM_STAMPS", "-DGA_STAMPS"] + sys.argv[1:])
+print("library", TAG)
 scen = importlib.import_module("gym-exploration-2d_amd.scenarios")
 B = importlib.import_module("gym-exploration-2d_amd.batched_env").BatchedCollisionAvoidanceEnv
 GA3C = importlib.import_module("gym-exploration-2d_amd.ga3c").GA3CCADRLPolicy
