@@ -194,7 +194,7 @@ struct Lds3 {
     int* wall;        // [4 AS] (OBST only) wall_prep3's per-agent cell / window / row half-widths
     int* flag;     // [16] 0: a world was reset this step   1: OAS row chunks claimed   2: LP waves finished
                    //      3/4: some ego needed linearProgram3 this / the previous step   5/6: obstacle_lines_phase3's work list
-                   //      7, 8, 10: LaserScan: slab-test passes claimed / finished, sampling rounds claimed
+                   //      7, 8, 10: LaserScan: slab-test passes claimed / finished, sampling rounds claimed   11: LP batches claimed (OBST)
     float2* lpv;   // [AS] preferred (optimisation) velocity of each ego
     float2* lpc;   // [AS] pref velocity clipped to maxSpeed = LP start; LP result afterwards
     float* lpr;    // [AS] maxSpeed of the ego (LP radius)
@@ -1164,8 +1164,18 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
             // (cfg4: nearly every ego among rectangles is busy - median 35 of a workgroup's 36 RVO agents - so 70 % of the workgroups run
             // a second round of groups for a handful of egos.  Groups of FOUR lanes with four half-planes per lane - one round for up
             // to 64 egos, orca_lp_group_n<4, 4> - were measured slower: this phase 8.6 -> 9.4 us, tools/cfg4_timeline.py.)
-            for (int base = 0; base < cnt; base += NG) {
-                const int idx = base + g;
+            // Batches of NGW egos (one per lane group of a wave).  Free space: batch = the wave's own groups, at most one round
+            // in practice.  OBST (cfg4: 35 of a workgroup's 36 RVO egos are busy, 32 groups): the batches beyond the first round
+            // are CLAIMED (LDS counter) by whichever wave finishes its batch first instead of waiting for wave 0's.
+            for (int batch = wave; batch * NGW < cnt;) {
+                const int idx = batch * NGW + (g & (NGW - 1));
+                if (OBST) {
+                    int nb = 0;
+                    if ((tid & (CAGYM_WAVE - 1)) == 0) nb = NWAVES + __hip_atomic_fetch_add(&W.flag[11], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    batch = __builtin_amdgcn_readfirstlane(nb);  // (claimed before the batch is solved: the latency hides behind it)
+                } else {
+                    batch += NWAVES;
+                }
                 if (idx < cnt) {
                     worked = true;
                     const int a = W.lpk[idx];
@@ -1294,7 +1304,7 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
         } else if (agent_lane) {
             W.tmoved[tid] = 0;
         }
-        if (tid == NT - 1) { W.flag[1] = 0; W.flag[2] = 0; W.flag[4] = W.flag[3]; W.flag[3] = 0; W.flag[7] = 0; W.flag[8] = 0; W.flag[9] = 0; W.flag[10] = 0; }
+        if (tid == NT - 1) { W.flag[1] = 0; W.flag[2] = 0; W.flag[4] = W.flag[3]; W.flag[3] = 0; W.flag[7] = 0; W.flag[8] = 0; W.flag[9] = 0; W.flag[10] = 0; W.flag[11] = 0; }
         __syncthreads();
         WGTRACE1(26);
         STAMP(4);
