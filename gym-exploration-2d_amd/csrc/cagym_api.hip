@@ -215,6 +215,7 @@ int cagym_create(const cagym_config* cfg, void** env_out) {
     D.N = (int)N; D.M = (int)M; D.S = (int)S; D.Kobs = cfg->max_obstacles;
     D.go_mode = cfg->game_over_mode; D.collide_static = cfg->collide_with_static; D.laserscan = cfg->laserscan;
     D.dt = cfg->dt;
+    D.inv_dt = 1.0 / cfg->dt;
     D.maxnb = cfg->rvo_max_neighbors > 0 ? cfg->rvo_max_neighbors : (int)M;  // RVOPolicy.py:15: Config.MAX_NUM_AGENTS_IN_ENVIRONMENT
     if (D.maxnb > (int)M - 1) D.maxnb = (int)M - 1;                            // there are at most M - 1 other agents
     int rc = CAGYM_OK;

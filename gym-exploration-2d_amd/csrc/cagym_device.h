@@ -27,6 +27,8 @@ struct CagymDev {
     int maxnb;  // RVO maxNeighbors (policies/RVOPolicy.py:15,25), 1 .. M - 1
     int ko;     // half-plane rows reserved per ego for obstacle lines: 2 * Kobs when RVO agents live among rectangles, else 0
     double dt;
+    double inv_dt;  // 1.0 / dt, divided on the host (IEEE, the double Python's `1 / DT` is): a kernel that divides it itself hoists the
+                    // quotient out of the step loop, finds no register for it and reloads it from scratch memory inside S1 every step
     // scenario pool [S, ...]
     const double* sc_agents6;
     const double* sc_heading0;  // may be null

@@ -194,7 +194,7 @@ struct Lds3 {
     int* wall;        // [4 AS] (OBST only) wall_prep3's per-agent cell / window / row half-widths
     int* flag;     // [16] 0: a world was reset this step   1: OAS row chunks claimed   2: LP waves finished
                    //      3/4: some ego needed linearProgram3 this / the previous step   5/6: obstacle_lines_phase3's work list
-                   //      7, 8, 10: LaserScan: slab-test passes claimed / finished, sampling rounds claimed   11: LP batches claimed (OBST)
+                   //      7, 8, 10: LaserScan: slab-test passes claimed / finished, sampling rounds claimed
     float2* lpv;   // [AS] preferred (optimisation) velocity of each ego
     float2* lpc;   // [AS] pref velocity clipped to maxSpeed = LP start; LP result afterwards
     float* lpr;    // [AS] maxSpeed of the ego (LP radius)
@@ -803,7 +803,8 @@ __device__ __forceinline__ void ego_obs3(const CagymDev& D, const Lds3& W, float
         e[1] = make_float4((float)W.the[a], (float)W.th[a], (float)px, (float)py);
         e[2] = make_float4((float)W.tpref[a], (float)nobs, ST_POLICY(W.tst[a]) == CAGYM_POL_LEARNING ? 1.f : 0.f, 0.f);
     } else {
-        e[0] = e[1] = e[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);  // (a chained assignment reads e[1] back from memory)
+        e[0] = z; e[1] = z; e[2] = z;
     }
 }
 
@@ -1124,7 +1125,12 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
         asm volatile("" : "+v"(tid));
         const int wave = tid >> 6;
         const bool agent_lane = tid < nagents;
-        const size_t aidx = (size_t)C.world * M + C.slot;
+        // the flat agent index as an opaque 32-bit value per step: as a loop invariant the compiler keeps several 64-bit forms of it
+        // (x 1, x 4, + base) alive across the whole loop - in the kernels held to 128 VGPRs they went to scratch memory and came back
+        // in S2 one round trip per output store (N * M < 2^31: cagym_create)
+        int aidx32 = C.world * M + C.slot;
+        asm volatile("" : "+v"(aidx32));
+        const size_t aidx = (size_t)(unsigned)aidx32;
         const CagymOut o_prev = out_slice3(out, t > 0 ? t - 1 : 0, (size_t)D.N, NM, M);  // rows of step t-1 (used when t > 0)
         const CagymOut o = out_slice3(out, t, (size_t)D.N, NM, M);
 #ifndef CAGYM_NO_LAG_PRIORITY
@@ -1163,19 +1169,12 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
             PMARK("C_lp_loop");
             // (cfg4: nearly every ego among rectangles is busy - median 35 of a workgroup's 36 RVO agents - so 70 % of the workgroups run
             // a second round of groups for a handful of egos.  Groups of FOUR lanes with four half-planes per lane - one round for up
-            // to 64 egos, orca_lp_group_n<4, 4> - were measured slower: this phase 8.6 -> 9.4 us, tools/cfg4_timeline.py.)
-            // Batches of NGW egos (one per lane group of a wave).  Free space: batch = the wave's own groups, at most one round
-            // in practice.  OBST (cfg4: 35 of a workgroup's 36 RVO egos are busy, 32 groups): the batches beyond the first round
-            // are CLAIMED (LDS counter) by whichever wave finishes its batch first instead of waiting for wave 0's.
-            for (int batch = wave; batch * NGW < cnt;) {
-                const int idx = batch * NGW + (g & (NGW - 1));
-                if (OBST) {
-                    int nb = 0;
-                    if ((tid & (CAGYM_WAVE - 1)) == 0) nb = NWAVES + __hip_atomic_fetch_add(&W.flag[11], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    batch = __builtin_amdgcn_readfirstlane(nb);  // (claimed before the batch is solved: the latency hides behind it)
-                } else {
-                    batch += NWAVES;
-                }
+            // to 64 egos, orca_lp_group_n<4, 4> - were measured slower: this phase 8.6 -> 9.4 us, tools/cfg4_timeline.py.  So was
+            // letting the waves CLAIM the batches beyond the first round from an LDS counter, whichever finishes first: the second
+            // round left wave 0 - its stamp 8.7 -> 6.1 us - but the workgroup's duration stayed at 45 us and the free-space roll-out
+            // kernel picked up 12 bytes of scratch from the changed loop.)
+            for (int base = 0; base < cnt; base += NG) {
+                const int idx = base + g;
                 if (idx < cnt) {
                     worked = true;
                     const int a = W.lpk[idx];
@@ -1267,7 +1266,7 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
                         case CAGYM_POL_CARRL: d0 = 1.0; d1 = carrl_heading(ext ? (int)ext[2 * aidx] : 0); break;
                         case CAGYM_POL_RVO: {
                             const float2 v = W.lpc[tid];  // LP result, or the clipped preferred velocity of an ego that needed none
-                            orca_post(A, v.x, v.y, D.dt, d0, d1, &hint);
+                            orca_post(A, v.x, v.y, D.dt, D.inv_dt, d0, d1, &hint);
                             break;
                         }
                     }
@@ -1276,6 +1275,16 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
                 }
                 asm volatile("" :: "v"(a0), "v"(a1));
                 WAVETRACE(t, 15);
+                if (TWO && !OBST) {
+                    // M = 20 and the run-time-M kernels are held to 128 VGPRs (the whole launch co-resident) and the compiler kept the
+                    // hint's three doubles alive through take_action in SCRATCH memory: two dependent round trips of ~600 cycles on the
+                    // chain.  The LP scratch is dead here (every LP wave is done, phase A's keys come after the next barrier): the hint
+                    // waits there instead (an LDS round trip; the empty statement keeps the compiler from forwarding the stores)
+                    HeadingHint* hl = reinterpret_cast<HeadingHint*>(W.lp3) + tid;
+                    *hl = hint;
+                    asm volatile("" ::: "memory");
+                    moved = take_action<false>(A, a0, a1, D.dt, hl);
+                } else
                 moved = take_action<false>(A, a0, a1, D.dt, &hint);
             }
             PMARK("D_s1_end");
@@ -1304,7 +1313,7 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
         } else if (agent_lane) {
             W.tmoved[tid] = 0;
         }
-        if (tid == NT - 1) { W.flag[1] = 0; W.flag[2] = 0; W.flag[4] = W.flag[3]; W.flag[3] = 0; W.flag[7] = 0; W.flag[8] = 0; W.flag[9] = 0; W.flag[10] = 0; W.flag[11] = 0; }
+        if (tid == NT - 1) { W.flag[1] = 0; W.flag[2] = 0; W.flag[4] = W.flag[3]; W.flag[3] = 0; W.flag[7] = 0; W.flag[8] = 0; W.flag[9] = 0; W.flag[10] = 0; }
         __syncthreads();
         WGTRACE1(26);
         STAMP(4);

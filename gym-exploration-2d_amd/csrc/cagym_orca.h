@@ -200,7 +200,7 @@ __device__ __forceinline__ float4 orca_line(float pex, float pey, float vex, flo
 }
 
 // Agent::update (fp32) and the fp64 tail of RVOPolicy.find_next_action (RVOPolicy.py:91-106).
-__device__ inline void orca_post(const Agent& A, float nvx, float nvy, double dt, double& out_speed, double& out_dh,
+__device__ inline void orca_post(const Agent& A, float nvx, float nvy, double dt, double inv_dt, double& out_speed, double& out_dh,
                                  HeadingHint* hint = nullptr) {
     const float time_step = (float)dt;
     float npx = (float)A.px + nvx * time_step, npy = (float)A.py + nvy * time_step;  // Agent::update, fp32
@@ -211,7 +211,7 @@ __device__ inline void orca_post(const Agent& A, float nvx, float nvy, double dt
     if (nh < 0) nh += 2 * kPi;
     double dh = wrap_angle(nh - A.h);
     const double dpn = norm2(dpx, dpy);
-    double speed = 1 / dt * dpn;
+    double speed = inv_dt * dpn;  // 1 / dt * |dp| (RVOPolicy.py:104), inv_dt = the double 1 / dt
     if (hint) {  // the move's own direction: the unicycle's new heading is this angle up to the fp32 rounding of dh
         // 1 / |dp| by v_rsq_f64 + two Newton steps (relative error ~1e-16: the hint's own budget is d^3/6 ~ 1e-19 + this)
         const double q = dot2(dpx, dpy, dpx, dpy);
@@ -237,7 +237,7 @@ __device__ inline void orca_solve(const float4* L, float4* P, int lane, int nn, 
     float nvx, nvy;
     int fail = orca_lp2(L, lane, nn, E.max_speed, E.pvx, E.pvy, false, nvx, nvy);
     if (fail < nn) orca_lp3(L, P, lane, nn, fail, E.max_speed, nvx, nvy);
-    orca_post(A, nvx, nvy, dt, out_speed, out_dh, hint);
+    orca_post(A, nvx, nvy, dt, 1 / dt, out_speed, out_dh, hint);
 }
 
 // RVOPolicy.find_next_action for the agent on `lane`; base = first lane of its world, n = agents in
