@@ -419,13 +419,20 @@ def main():
         torch.cuda.synchronize(device)
 
     def timed_block():
-        """EXACTLY --steps steps between two barrier + synchronize brackets; returns (wall s maxed over ranks, device ms, launches)."""
+        """EXACTLY --steps steps between two barrier + synchronize brackets; returns (wall s maxed over ranks, device ms or None,
+        launches).  Every SECOND block also carries the HIP events of `launch_ms_hip_events`: recording one costs the host 4 us
+        (tools/host_overhead.py) - 2 % of a 20-step block - and is instrumentation, not workload, so the wall-clock figure is the
+        median of the blocks WITHOUT events and the device figure the median of the blocks with them."""
+        with_events = stats_state["block"] % 2 == 1
         barrier()
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        if with_events:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
-        ev0.record()
+        if with_events:
+            ev0.record()
         launches = run(args.steps)
-        ev1.record()
+        if with_events:
+            ev1.record()
         barrier()
         el = time.perf_counter() - t0
         stats_state["block"] += 1
@@ -433,7 +440,7 @@ def main():
             t = torch.tensor([el], dtype=torch.float64, device=device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
-        return el, ev0.elapsed_time(ev1), launches
+        return el, (ev0.elapsed_time(ev1) if with_events else None), launches
 
     run(args.warmup)
     barrier()
@@ -474,7 +481,7 @@ def main():
         more_blocks(max(0, args.repeats - 1))
     else:  # at least 5 blocks, and short blocks are repeated until the timed blocks cover 2 s whatever --steps is
         while len(blocks) < 50000:
-            covered = sum(b[0] for b in blocks)
+            covered = sum(b[0] for b in blocks if b[1] is None)  # the wall clock is taken from the blocks without HIP events
             med = sorted(b[0] for b in blocks)[len(blocks) // 2]
             n = max(5 - len(blocks), int((2.0 - covered) / max(med, 1e-6)) + 1 if covered < 2.0 else 0)
             if more_blocks(min(n, 50000 - len(blocks))) == 0:
@@ -482,10 +489,10 @@ def main():
     if world_size > 1:
         gather_stats(env, force=True)  # the final counters
         barrier()
-    walls = sorted(b[0] for b in blocks)
+    walls = sorted(b[0] for b in blocks if b[1] is None)  # the blocks without HIP events
     elapsed = walls[len(walls) // 2]  # median block
-    dev_sorted = sorted(b[1] for b in blocks)
-    dev_ms = dev_sorted[len(dev_sorted) // 2]
+    dev_sorted = sorted(b[1] for b in blocks if b[1] is not None)
+    dev_ms = dev_sorted[len(dev_sorted) // 2] if dev_sorted else 1e3 * elapsed  # (--repeats 1: no block with events)
     launches = blocks[0][2]
 
     st = stats_mod.summarize(gathered if gathered is not None else env.packed_episode_stats())
@@ -529,7 +536,7 @@ def main():
                        "worlds_per_gpu": N, "agents": M, "steps_per_launch": steps_per_launch,
                        "launch_mode": launch_mode,
                        "parallelism": "worlds sharded x%d, no data-path collective" % world_size},
-            "repeats": len(blocks), "timing": "median of %d timed blocks of %d steps" % (len(blocks), args.steps),
+            "repeats": len(blocks), "timing": "wall clock: median of the %d timed blocks of %d steps without HIP events; launch_ms_hip_events: median of the %d blocks in between that carry them" % (len(walls), args.steps, len(dev_sorted)),
             "ms_per_step_min": 1e3 * walls[0] / args.steps, "ms_per_step_max": 1e3 * walls[-1] / args.steps,
             "timed_region_s": sum(walls),
             "rccl_ranks": world_size if (world_size > 1 and backend == "nccl") else 0,

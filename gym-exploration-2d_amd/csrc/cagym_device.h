@@ -127,7 +127,12 @@ __device__ __forceinline__ void ref_axes(const Agent& A, double& prx, double& pr
 
 // Agent.__init__ (agent.py:9-109) from scenario row `s` (index into the [S*M] pool).
 __device__ __forceinline__ void init_agent(const CagymDev& D, Agent& A, int sidx, int slot, bool active) {
-    const double* s6 = D.sc_agents6 + ((size_t)sidx * D.M + slot) * 6;
+    // every load of the scenario row first (one round trip to HBM: this runs inside the step kernels' S2 when a world restarts;
+    // with the policy / dynamics / coefficient loads behind the atan2 below they were a second, dependent one)
+    const size_t k = (size_t)sidx * D.M + slot;
+    const double* s6 = D.sc_agents6 + k * 6;
+    const double coop = D.sc_coop[k];
+    const uint32_t pol = (uint32_t)D.sc_policy[k], dyn = (uint32_t)D.sc_dyn[k];
     A.px = s6[0];
     A.py = s6[1];
     A.gx = s6[2];
@@ -139,13 +144,12 @@ __device__ __forceinline__ void init_agent(const CagymDev& D, Agent& A, int sidx
     A.dh = 0.0;
     A.aux0 = A.aux1 = 0.0;
     A.a0 = A.a1 = 0.f;
-    size_t k = (size_t)sidx * D.M + slot;
     A.h = D.sc_heading0 ? D.sc_heading0[k] : atan2(A.gy - A.py, A.gx - A.px);
-    A.coop = D.sc_coop[k];
+    A.coop = coop;
     A.trem = 3.0 * ((norm2(A.px - A.gx, A.py - A.gy) - 0.75) / A.pref);  // agent.py:59-63
     A.t = 0.0;
     A.step = 0;
-    A.st = ((uint32_t)D.sc_policy[k] << 8) | ((uint32_t)D.sc_dyn[k] << 12) | (active ? CAGYM_FLAG_ACTIVE : 0u);
+    A.st = (pol << 8) | (dyn << 12) | (active ? CAGYM_FLAG_ACTIVE : 0u);
     double prx, pry;
     update_ego_frame(A, prx, pry);
 }
