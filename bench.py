@@ -8,11 +8,13 @@ pool of 8x4096 scenarios.  One "step" = one env.step() of all worlds of a rank. 
 tensors to HBM slice t of a trajectory buffer).
 
 Timing (repeats, median): after --warmup untimed steps the block of EXACTLY --steps steps is timed
-`repeats` times, each time bracketed by barrier + torch.cuda.synchronize() on both sides and max-reduced over ranks;
-`ms_per_step` / `value` are the MEDIAN block (min / max beside it).  Short blocks are repeated until the timed blocks
-cover at least 2 s whatever --steps is (the driver's 20-step block is 0.2 ms: ~9000 blocks).  ONE clock: `value`,
-`ms_per_step` and `roofline.achieved` / `frac` all come from the wall-clock median block; the HIP-event duration of the
-same blocks is printed beside it as `roofline.launch_ms_hip_events` / `frac_hip_events`.
+`repeats` times, each time bracketed by barrier + torch.cuda.synchronize() on both sides and max-reduced over ranks (the
+clock of a rank stops when its own closing synchronize returns, the closing barrier follows: the collective's latency is
+the bench's, not the K steps'); `ms_per_step` / `value` are the MEDIAN block (min / max beside it).  Short blocks are
+repeated until the timed blocks cover at least 2 s whatever --steps is (the driver's 20-step block is 0.2 ms: ~9000
+blocks).  ONE clock: `value`, `ms_per_step` and `roofline.achieved` / `frac` all come from the wall-clock median block;
+HIP events ride in every SECOND block only (recording one costs the host 4 us) and give `roofline.launch_ms_hip_events` /
+`frac_hip_events`; the wall clock is the median of the blocks without them.
 
 Multi-GPU: `python bench.py --gpus N` with no RANK in the environment starts N one-GPU ranks itself
 (torch.distributed.run, before anything touches the GPU in this process); under a launcher (RANK set) it is one rank.
@@ -433,8 +435,13 @@ def main():
         launches = run(args.steps)
         if with_events:
             ev1.record()
-        barrier()
+        # closing bracket: synchronize, read the clock, THEN the barrier - the rank's K steps are done when its own synchronize returns,
+        # and the MAX over ranks below is the whole job's time; the barrier collective's own latency (tens of microseconds against a
+        # 212 us block of 20 steps) is the bench's, not the workload's.  (One rank: the bracket is the synchronize alone, as before.)
+        torch.cuda.synchronize(device)
         el = time.perf_counter() - t0
+        if world_size > 1:
+            dist.barrier()
         stats_state["block"] += 1
         if world_size > 1:
             t = torch.tensor([el], dtype=torch.float64, device=device)
