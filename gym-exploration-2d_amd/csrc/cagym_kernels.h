@@ -600,23 +600,30 @@ __device__ __forceinline__ void ga3c_state_row(const CagymDev& D, int max_observ
     float* o = out + orow * 76;
     if (have)
         for (int c = j; c < 76; c += LPA) o[c] = 0.f;
-    const int n = have ? D.n_agents[world] : 0;
-    const bool ego_live = have && i < n;
+    // every load the lane may need is requested before the first is looked at (slot indices clamped into the world: in bounds whatever
+    // the world's agent count is) - the agent count, the ego's and the other agent's records come back in ONE round trip instead of three
     const size_t base = (size_t)world * D.M;
-    double px = 0, py = 0, ri = 0, prx = 0, pry = 0, orx = 0, ory = 0;
-    double dx = 0, dy = 0, rj = 0, ed = 0, k1 = 0, k2 = 0;
+    const size_t oj = base + (size_t)(j < D.M ? j : D.M - 1);
+    int n = 0;
+    double px = 0, py = 0, ri = 0, gxa = 0, gya = 0, pxj = 0, pyj = 0, rj = 0, vxj = 0, vyj = 0;
+    if (have) {
+        n = D.n_agents[world];
+        px = D.px[a]; py = D.py[a]; ri = D.radius[a]; gxa = D.gx[a]; gya = D.gy[a];
+        pxj = D.px[oj]; pyj = D.py[oj]; rj = D.radius[oj]; vxj = D.vx[oj]; vyj = D.vy[oj];
+    }
+    const bool ego_live = have && i < n;
+    double prx = 0, pry = 0, orx = 0, ory = 0;
+    double dx = 0, dy = 0, ed = 0, k1 = 0, k2 = 0;
     const bool mine = ego_live && j < n && j != i;
     if (ego_live) {
-        px = D.px[a]; py = D.py[a]; ri = D.radius[a];
-        const double gx = D.gx[a] - px, gy = D.gy[a] - py;
+        const double gx = gxa - px, gy = gya - py;
         const double dist = sqrt(gx * gx + gy * gy);
         prx = gx; pry = gy;
         if (dist > 1e-8) { prx = gx / dist; pry = gy / dist; }
         orx = -pry; ory = prx;
     }
     if (mine) {
-        dx = D.px[base + j] - px; dy = D.py[base + j] - py;
-        rj = D.radius[base + j];
+        dx = pxj - px; dy = pyj - py;
         ed = norm2(dx, dy) - ri - rj;
         k1 = -(rint(ed * 100.0) / 100.0);
         k2 = dot2(dx, dy, orx, ory);
@@ -635,7 +642,7 @@ __device__ __forceinline__ void ga3c_state_row(const CagymDev& D, int max_observ
         }
         const int row = before - drop;
         if (row >= 0) {
-            const double vx = D.vx[base + j], vy = D.vy[base + j];
+            const double vx = vxj, vy = vyj;
             float* r = o + 6 + 7 * row;
             r[0] = (float)dot2(dx, dy, prx, pry);
             r[1] = (float)k2;
