@@ -357,6 +357,14 @@ __global__ void __launch_bounds__(256, 2) k_ga3c_forward_mfma(const float* __res
     static_assert(2 * HB + 10 * 7 * AG <= HB + GA_W * AG && 5 * AG * 12 <= HB, "LDS aliasing");
     const int n = threadIdx.x, tile = blockIdx.x * AG;
     const int lane = n & 63, wave = n >> 6, half = lane >> 5, j = lane & 31;
+    // the agent behind each of the tile's rows and its preferred speed, requested now for the action write at the very end (two
+    // dependent loads from HBM that used to sit behind the last layer: ~1 us of the kernel's tail)
+    int act_a = 0;
+    double act_pref = 0.0;
+    if (n < AG && tile + n < B) {
+        act_a = agent_idx[tile + n];
+        act_pref = pref[act_a];
+    }
     // list_ctr != null (cagym_ga3c_act): the state rows are stored by place in the list - row tile + g, no index look-up in front
     const bool by_place = list_ctr != nullptr;
     for (int e = n; e < AG * 5; e += 256) {
@@ -491,7 +499,7 @@ __global__ void __launch_bounds__(256, 2) k_ga3c_forward_mfma(const float* __res
     }
     __syncthreads();
     if (n < AG && tile + n < B) {
-        const int a = agent_idx[tile + n];
+        const int a = act_a;
         float mx = logit[n * 12];
         int best = 0;
         for (int o = 1; o < 11; o++)
@@ -507,7 +515,7 @@ __global__ void __launch_bounds__(256, 2) k_ga3c_forward_mfma(const float* __res
         else if (best < 8) { a0 = 0.5; a1 = -kPi / 6 + (double)(best - 5) * (kPi / 6); }
         else { a0 = 0.0; a1 = -kPi / 6 + (double)(best - 8) * (kPi / 6); }
         if (ext_actions) {
-            ext_actions[2 * (size_t)a] = (float)(pref[a] * a0);
+            ext_actions[2 * (size_t)a] = (float)(act_pref * a0);
             ext_actions[2 * (size_t)a + 1] = (float)a1;
         }
     }
