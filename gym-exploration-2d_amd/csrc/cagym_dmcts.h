@@ -263,7 +263,8 @@ __global__ void __launch_bounds__(DM_THREADS, 4) k_dmcts_plan(IgDev G, DmParams 
     __shared__ int cfeas[9];
     __shared__ double rew[DM_MAXSIMS];
     __shared__ uint8_t btail[DM_MAXH];
-    __shared__ int sh_sel, sh_pick, sh_n;
+    __shared__ int sh_sel, sh_pick, sh_n, sh_depth;
+    __shared__ int sh_path[DM_MAXH + 2];
     __shared__ int picks[DM_MAXCOMM];
     __shared__ int dist_idx[DM_MAXR][DM_MAXCOMM];
     __shared__ double dist_q[DM_MAXR][DM_MAXCOMM];
@@ -326,10 +327,12 @@ __global__ void __launch_bounds__(DM_THREADS, 4) k_dmcts_plan(IgDev G, DmParams 
                 // (the children of a node are scored side by side on the lanes of wave 0 - a logarithm, a division and a square root
                 //  each; lane 0 alone walked up to 4 levels x 9 children - and the first maximum in child order is taken, as `if u > best`)
                 if (wave == 0) {
-                    int node = 0;
+                    int node = 0, depth = 0;
                     for (;;) {
+                        if (lane == 0) sh_path[depth] = node;  // the walk from the root: back-propagation climbs it without reloading parents
                         const int nc = T[node].nchild;  // uniform
                         if (nc <= 0) break;
+                        depth++;
                         const double n_p = T[node].Nv;
                         const int c0 = T[node].child0;
                         double u = -INFINITY;
@@ -346,7 +349,7 @@ __global__ void __launch_bounds__(DM_THREADS, 4) k_dmcts_plan(IgDev G, DmParams 
                         }
                         node = c0 + __shfl(bi, 0, 64);
                     }
-                    if (lane == 0) sh_sel = node;
+                    if (lane == 0) { sh_sel = node; sh_depth = depth; }
                 }
                 __syncthreads();
                 const int s = sh_sel;
@@ -414,7 +417,8 @@ __global__ void __launch_bounds__(DM_THREADS, 4) k_dmcts_plan(IgDev G, DmParams 
                 __syncthreads();
                 const double avg = red[0];
                 __syncthreads();
-                for (int a = T[s].parent; a >= 0; a = T[a].parent) {  // uniform walk
+                for (int d = sh_depth - 1; d >= 0; d--) {  // the selected node's ancestors, parent first (= the walk T[a].parent, without its loads)
+                    const int a = sh_path[d];
                     const bool better = best > T[a].best;
                     __syncthreads();
                     if (better)
@@ -435,18 +439,22 @@ __global__ void __launch_bounds__(DM_THREADS, 4) k_dmcts_plan(IgDev G, DmParams 
                 //      those with a roll-out, q = mu^2 -------------------------------------------------------------------------
                 const int total = nn[0];
                 int mypick[DM_MAXCOMM];  // the rounds' winners (uniform: every thread derives them from the waves' candidates)
+                // a thread's first two candidates (nodes 1 + tid and 1 + tid + DM_THREADS: all of them at the experiment's budget of 271
+                // nodes) are fetched ONCE for all comm_n rounds - each round used to start with its own round trip to the node pool
+                const int ci0 = 1 + tid, ci1 = 1 + tid + DM_THREADS;
+                const double cm0 = ci0 < total ? T[ci0].mu : 0.0, cm1 = ci1 < total ? T[ci1].mu : 0.0;
 #pragma unroll
                 for (int round = 0; round < DM_MAXCOMM; round++) {  // (unrolled to its compile-time bound: mypick stays in registers)
                     if (round >= P.comm_n) break;
                     double bm = -INFINITY;
                     int bi = 0x7fffffff;
-                    for (int i = 1 + tid; i < total; i += DM_THREADS) {
+                    for (int i = ci0; i < total; i += DM_THREADS) {  // ascending i, as before: the first maximum wins
                         bool taken = false;
 #pragma unroll
                         for (int q = 0; q < DM_MAXCOMM; q++)
                             if (q < round) taken |= mypick[q] == i;
                         if (taken) continue;
-                        const double m = T[i].mu;
+                        const double m = i == ci0 ? cm0 : (i == ci1 ? cm1 : T[i].mu);
                         if (m > bm || (m == bm && i < bi)) { bm = m; bi = i; }
                     }
                     // arg-max over (mu desc, index asc): inside the wave by lane shuffles, across the 4 waves through LDS - one
