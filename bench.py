@@ -520,6 +520,7 @@ def main():
         if (N, M, policy, args.per_step_launch) == (4096, 10, "rvo", False) and os.path.exists(rp):
             replay = json.load(open(rp))
         traffic_per_agent_step = (replay["hbm_bytes_per_agent_step"] + replay.get("hbm_bytes_per_agent_per_launch", 0.0) / steps_per_launch) if replay else None
+        short_launch = steps_per_launch <= 32  # the driver's command: one 20-step launch per block
         if replay:
             traffic = traffic_per_agent_step * N * M * steps_per_launch / (launch_ms * 1e-3) / 1e9  # GB/s, comparable to `achieved`
         # measured device-to-device copy ceiling next to the vendor HBM figure: read + write of 1 GiB
@@ -559,9 +560,10 @@ def main():
                          "traffic_source": None if traffic is None else
                          "replayed from profiles/r3/headline_pmc.json (rocprofv3 --pmc passes of this shape: FETCH_SIZE x2 + WRITE_SIZE per agent-step), not measured in this run",
                          # what actually bounds the kernel (the HBM fraction above is the metric BASELINE.json asks for): VALU issue
-                         "valu_busy": replay["valu_busy"] if replay else None,
-                         "valu_insts_per_agent_step": replay["valu_insts_per_agent_step"] if replay else None,
-                         "valu_source": None if not replay else "replayed from profiles/r3/headline_pmc.json (SQ_ACTIVE_INST_VALU, SQ_INSTS_VALU, GRBM_GUI_ACTIVE of the %s-step launches), not measured in this run" % replay.get("steps_per_launch", "512"),
+                         # (a 20-step launch ends with its slowest workgroup: its own counters, where the profile has them)
+                         "valu_busy": None if not replay else replay.get("valu_busy_20_step_launches", replay["valu_busy"]) if short_launch else replay["valu_busy"],
+                         "valu_insts_per_agent_step": None if not replay else replay.get("valu_insts_per_agent_step_20_step_launches", replay["valu_insts_per_agent_step"]) if short_launch else replay["valu_insts_per_agent_step"],
+                         "valu_source": None if not replay else "replayed from profiles/r3/headline_pmc.json (SQ_ACTIVE_INST_VALU, SQ_INSTS_VALU, GRBM_GUI_ACTIVE of the %s-step launches), not measured in this run" % ("20" if short_launch and "valu_busy_20_step_launches" in replay else replay.get("steps_per_launch", "512")),
                          "kernel": kernel_name,
                          "clock": "wall-clock median block (the clock of `value` and `ms_per_step`: frac = alg_bytes_per_agent_step x agents x worlds / ms_per_step / peak)",
                          "launch_ms": launch_ms, "launch_ms_min": 1e3 * walls[0] / launches, "launch_ms_max": 1e3 * walls[-1] / launches,
