@@ -8,8 +8,10 @@ Translation units (compiled in parallel, objects cached under csrc/build/ by sou
   cagym_k3_tu.hip x 12               one per generation-3 specialisation (cagym_launch3.h: CAGYM_K3_SPECS x OBST)
 """
 import concurrent.futures
+import functools
 import hashlib
 import os
+import re
 import subprocess
 import sys
 
@@ -17,10 +19,23 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(CSRC, "libcagym_hip.so")
-HEADERS = ["cagym_device.h", "cagym_orca.h", "cagym_kernels.h", "cagym_kernels3.h", "cagym_launch3.h", "cagym_ig.h", "cagym_ga3c.h",
-           "cagym_gen.h", "cagym_dmcts.h", "../../include/cagym.h"]
-K3_HEADERS = ["cagym_device.h", "cagym_orca.h", "cagym_kernels.h", "cagym_kernels3.h", "cagym_launch3.h", "../../include/cagym.h"]
-K3_SPECS = [(256, 10, 4), (256, 10, 5), (256, 4, 0), (256, 20, 2), (256, 0, 0), (512, 0, 0)]  # = CAGYM_K3_SPECS
+K3_HEADERS = ["cagym_device.h", "cagym_trace.h", "cagym_spin.h", "cagym_orca.h", "cagym_kernels.h", "cagym_kernels3.h", "cagym_launch3.h",
+              "../../include/cagym.h"]
+HEADERS = K3_HEADERS + ["cagym_ig.h", "cagym_ga3c.h", "cagym_gen.h", "cagym_dmcts.h"]
+
+
+def _k3_specs():
+    """(lanes, compile-time M, worlds per workgroup) rows of CAGYM_K3_SPECS, read from cagym_launch3.h: ONE list for the C ABI's
+    dispatch table and for the translation units built here."""
+    text = open(os.path.join(CSRC, "cagym_launch3.h")).read()
+    m = re.search(r"#define\s+CAGYM_K3_SPECS\(X\)(.*)", text)
+    rows = [tuple(int(v) for v in r) for r in re.findall(r"X\(\s*(\d+)\s*,\s*(\d+)\s*,\s*(\d+)\s*\)", m.group(1))] if m else []
+    if not rows:
+        raise RuntimeError("CAGYM_K3_SPECS not found in cagym_launch3.h")
+    return rows
+
+
+K3_SPECS = _k3_specs()
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wno-unused-value",
@@ -44,8 +59,17 @@ def _torch_lib_dir():
     return os.path.join(os.path.dirname(torch.__file__), "lib")
 
 
+@functools.lru_cache(maxsize=None)
+def _hipcc_version():
+    try:
+        return subprocess.run([os.environ.get("HIPCC", "hipcc"), "--version"], capture_output=True, text=True).stdout
+    except OSError:
+        return "?"
+
+
 def _digest(src, defs, headers, extra):
     h = hashlib.sha256()
+    h.update(_hipcc_version().encode())  # objects of another compiler are stale
     for f in [src] + headers:
         with open(os.path.join(CSRC, f), "rb") as fh:
             h.update(fh.read())

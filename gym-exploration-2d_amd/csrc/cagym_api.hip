@@ -36,6 +36,7 @@ struct Env {
     uint32_t* ig_any = nullptr;
     int32_t* gen_failed = nullptr;  // device word: agents whose rejection loop hit max_tries (cagym_generate_scenarios)
     int32_t* ga3c_ctr = nullptr;    // device words of cagym_ga3c_act's list (k_ga3c_select): ticket, list start, list length
+    int32_t* status_host = nullptr; // host-mapped word the kernels' bounded waits report into (CagymDev::dev_status, cagym_spin.h)
     bool ig_ready = false;
     int any_rvo = 1;
     int obst_rvo = 0;    // RVO agents in worlds with rectangles: the kernels build obstacle half-planes (OBST instantiations)
@@ -75,7 +76,19 @@ struct DeviceGuard {
 };
 #define DEVGUARD(e)                                                                                        \
     DeviceGuard _guard((e)->cfg.device);                                                                   \
-    if (_guard.status != hipSuccess) return fail(e, CAGYM_E_HIP, std::string("hipSetDevice: ") + hipGetErrorString(_guard.status))
+    if (_guard.status != hipSuccess) return fail(e, CAGYM_E_HIP, std::string("hipSetDevice: ") + hipGetErrorString(_guard.status)); \
+    if (int _rc = device_status(e)) return _rc
+
+// A kernel whose bounded intra-workgroup wait expired (cagym_spin.h) wrote its CAGYM_DEVERR_* code into the handle's host-mapped
+// status word: the launches since then produced void results.  Every launching entry point refuses to go on (the word is sticky
+// until cagym_destroy: the state on the device is not trustworthy any more).
+int device_status(Env* e) {
+    const int32_t code = e->status_host ? *reinterpret_cast<volatile int32_t*>(e->status_host) : 0;
+    if (code == CAGYM_DEVERR_NONE) return CAGYM_OK;
+    return fail(e, CAGYM_E_DEVICE, std::string("a kernel of an earlier launch gave up a bounded wait (") +
+                                       (code == CAGYM_DEVERR_LP_WAIT ? "LP waves" : code == CAGYM_DEVERR_LASER_WAIT ? "LaserScan passes" : "unknown") +
+                                       "): results since then are void, destroy the handle");
+}
 
 template <typename T>
 int dalloc(Env* e, T** p, size_t n) {
@@ -196,6 +209,8 @@ int cagym_create(const cagym_config* cfg, void** env_out) {
     if (cfg->max_agents < 2 || cfg->max_agents > 32)
         return fail(nullptr, CAGYM_E_UNSUPPORTED, "max_agents must be in [2, 32] (a world may not straddle a wavefront)");
     if (cfg->n_scenarios < cfg->n_worlds) return fail(nullptr, CAGYM_E_INVALID, "n_scenarios must be >= n_worlds");
+    if ((long long)cfg->n_worlds * cfg->max_agents >= (1ll << 31) || (long long)cfg->n_scenarios * cfg->max_agents >= (1ll << 31))
+        return fail(nullptr, CAGYM_E_UNSUPPORTED, "n_worlds * max_agents (and n_scenarios * max_agents) must stay below 2^31: the kernels keep flat agent indices in 32 bits");
     if (cfg->max_obstacles < 0 || !(cfg->dt > 0)) return fail(nullptr, CAGYM_E_INVALID, "bad max_obstacles / dt");
     if (cfg->rvo_max_neighbors < 0) return fail(nullptr, CAGYM_E_INVALID, "rvo_max_neighbors must be >= 0 (0 = max_agents)");
     int ndev = 0;
@@ -244,6 +259,18 @@ int cagym_create(const cagym_config* cfg, void** env_out) {
     A(dalloc(e, &D.stat_steps, N)); A(dalloc(e, &D.stat_outcomes, N * 3));
     A(dalloc(e, &e->ga3c_ctr, 4));  // at creation: cagym_ga3c_act may run inside a stream capture (no allocation there)
 #undef A
+    {   // the kernels' status word: pinned host memory mapped into the device's address space (written only when a bounded wait expires)
+        void* hp = nullptr;
+        void* dp = nullptr;
+        if (hipHostMalloc(&hp, 64, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) {
+            if (hp) (void)hipHostFree(hp);
+            cagym_destroy(e);
+            return fail(nullptr, CAGYM_E_NOMEM, "hipHostMalloc of the device status word failed");
+        }
+        memset(hp, 0, 64);
+        e->status_host = reinterpret_cast<int32_t*>(hp);
+        D.dev_status = reinterpret_cast<int32_t*>(dp);
+    }
     e->err.clear();
     size_t lds = cagym_lds_bytes((int)M);
     if (lds > 160 * 1024) { cagym_destroy(e); return fail(nullptr, CAGYM_E_UNSUPPORTED, "LDS budget exceeded"); }
@@ -308,6 +335,7 @@ int cagym_destroy(void* env) {
     if (!e) return CAGYM_OK;
     for (void* p : e->allocs)
         if (p) (void)hipFree(p);
+    if (e->status_host) (void)hipHostFree(e->status_host);
     delete e;
     return CAGYM_OK;
 }
@@ -678,12 +706,22 @@ int cagym_ga3c_act(void* env, const float* weights, int max_observed, void* work
     float* state = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(work) + 256 + a16(total * sizeof(int32_t)));
     // no memset in front of the chain: the handle's ticket words carry the list from call to call (k_ga3c_select)
     uint32_t* ctr = reinterpret_cast<uint32_t*>(e->ga3c_ctr);
+    // a launch that fails cuts the chain: the forward kernel is the one that starts the next list, so the ticket words are
+    // re-zeroed (on the same stream) before the error is returned and the next call starts from an empty list again
+    auto launched = [&](const char* what) -> int {
+        const hipError_t s = hipGetLastError();
+        if (s == hipSuccess) return CAGYM_OK;
+        (void)hipMemsetAsync(e->ga3c_ctr, 0, 4 * sizeof(int32_t), st);
+        return fail(e, CAGYM_E_HIP, std::string(what) + ": " + hipGetErrorString(s));
+    };
     hipLaunchKernelGGL(k_ga3c_select, dim3((unsigned)((total + 1023) / 1024)), dim3(1024), 0, st, e->D, idx, ctr);
+    if (int rc = launched("k_ga3c_select")) return rc;
     // the list length stays on the device: both kernels are launched for the worst case and leave beyond it
     launch_ga3c_state(e, max_observed, idx, (long long)total, ctr, state, st);
+    if (int rc = launched("k_ga3c_state")) return rc;
     hipLaunchKernelGGL(k_ga3c_forward_mfma, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, st, weights, state, idx, 0, e->ga3c_ctr + 2, e->D.pref,
                        ext_actions, (int32_t*)nullptr, (float*)nullptr, ctr);
-    HIPCHK(e, hipGetLastError());
+    if (int rc = launched("k_ga3c_forward_mfma")) return rc;
     return CAGYM_OK;
 }
 

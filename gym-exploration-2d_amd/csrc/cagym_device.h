@@ -51,6 +51,7 @@ struct CagymDev {
     float* ep_return;
     float* stat_return;
     int32_t *stat_episodes, *stat_steps, *stat_outcomes;
+    int32_t* dev_status;  // host-mapped word: CAGYM_DEVERR_* written by a kernel whose bounded wait expired (cagym_spin.h); 0 otherwise
 };
 
 struct CagymOut {

@@ -689,7 +689,9 @@ __global__ void __launch_bounds__(256) k_ga3c_state(CagymDev D, int max_observed
 // (round 3; a memset in front of every call was 4.9 us of cfg4's step): ctr[0] is a ticket counter that only ever grows
 // (unsigned, wraps), ctr[1] its value when this list began; a place in the list is ticket - ctr[1].  k_ga3c_state turns the
 // difference into the list length (ctr[2]) and the forward kernel - the last reader - starts the next list (ctr[1] = ctr[0]).
-// The words are the handle's, zero at creation; the chain replays from a captured graph as it is.
+// The words are the handle's, zero at creation; the chain replays from a captured graph as it is.  One call per handle in flight
+// (include/cagym.h): a chain that was cut short (a failed launch) leaves the list open - cagym_ga3c_act re-zeroes the words then -
+// and a place beyond the table (possible only then) is never stored.
 #ifndef CAGYM_K3_UNIT  // the generation-3 units include this header for its device functions only
 __global__ void __launch_bounds__(1024) k_ga3c_select(CagymDev D, int32_t* idx, uint32_t* ctr) {
     // one returning atomic per 1024-thread block (all of them hit one L2 address: per-wave atomics took 16 us for 81 920 slots)
@@ -712,6 +714,9 @@ __global__ void __launch_bounds__(1024) k_ga3c_select(CagymDev D, int32_t* idx, 
         for (int w = 0; w < 16; w++) wave_base[w] += base;
     }
     __syncthreads();
-    if (take) idx[wave_base[wave] + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)a;
+    if (take) {
+        const size_t place = (size_t)(unsigned)(wave_base[wave] + __popcll(m & ((1ull << lane) - 1ull)));
+        if (place < total) idx[place] = (int32_t)a;
+    }
 }
 #endif

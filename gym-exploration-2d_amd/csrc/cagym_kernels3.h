@@ -22,95 +22,35 @@
 #pragma once
 #include "cagym_kernels.h"
 
-// Diagnostic build only (-DCAGYM_STAMPS, never the shipped library): thread 0 of workgroup 0 accumulates
-// s_memtime deltas per phase into g_stamps; read back with cagym_debug_stamps().  The stamp values leave
-// the kernel only through this buffer and feed no output.
-#ifdef CAGYM_STAMPS
-__device__ unsigned long long g_stamps[16];
-#define STAMP(i)                                                                  \
-    do {                                                                          \
-        if (threadIdx.x == 0 && blockIdx.x == 0) {                                \
-            unsigned long long _t = __builtin_amdgcn_s_memtime();                 \
-            g_stamps[i] += _t - stamp_prev;                                       \
-            stamp_prev = _t;                                                      \
-        }                                                                         \
-    } while (0)
-#define STAMP_BEGIN() unsigned long long stamp_prev = __builtin_amdgcn_s_memtime()
-#else
-#define STAMP(i) do { } while (0)
-#define STAMP_BEGIN() do { } while (0)
-#endif
-
-// Second diagnostic build (-DCAGYM_WGTRACE, tools/launch_cost.py): thread 0 of EVERY workgroup records the 100 MHz
-// s_memrealtime clock at kernel entry, after the prologue, after each of the first 36 steps and at exit, plus its XCC id,
-// into g_wgtrace (read back with cagym_debug_wgtrace()).  Same rule: the values feed no output.
-#ifdef CAGYM_WGTRACE
-#define CAGYM_WGTRACE_MAXWG 4096
-#define CAGYM_WGTRACE_W 48
-__device__ unsigned long long g_wgtrace[CAGYM_WGTRACE_MAXWG * CAGYM_WGTRACE_W];
-#define WGTRACE(slot)                                                                                       \
-    do {                                                                                                    \
-        if (threadIdx.x == 0 && blockIdx.x < CAGYM_WGTRACE_MAXWG && (slot) < CAGYM_WGTRACE_W)               \
-            g_wgtrace[blockIdx.x * CAGYM_WGTRACE_W + (slot)] = __builtin_amdgcn_s_memrealtime();            \
-    } while (0)
-#define WGTRACE_BUSY(cnt)                                                                                   \
-    do {                                                                                                    \
-        if (threadIdx.x == 0 && blockIdx.x < CAGYM_WGTRACE_MAXWG)                                           \
-            g_wgtrace[blockIdx.x * CAGYM_WGTRACE_W + 39] += (unsigned long long)(cnt) << 8;                 \
-    } while (0)
-// sub-phases of a ONE-step launch (tools/cfg4_timeline.py): slots 20.. are free when n_steps == 1
-#define WGTRACE1(slot) do { if (n_steps == 1) WGTRACE(slot); } while (0)
-// lane 0 of wave 1 (the laser chunks of a one-step launch run on waves 1..)
-#define WGTRACE_W1(slot)                                                                                    \
-    do {                                                                                                    \
-        if (threadIdx.x == 64 && blockIdx.x < CAGYM_WGTRACE_MAXWG)                                          \
-            g_wgtrace[blockIdx.x * CAGYM_WGTRACE_W + (slot)] = __builtin_amdgcn_s_memrealtime();            \
-    } while (0)
-#else
-#define WGTRACE_W1(slot) do { } while (0)
-#define WGTRACE(slot) do { } while (0)
-#define WGTRACE_BUSY(cnt) do { } while (0)
-#define WGTRACE1(slot) do { } while (0)
-#endif
-
-// Third diagnostic build (-DCAGYM_WAVETRACE, tools/wave_trace.py): lane 0 of EVERY WAVE of one workgroup stamps s_memtime at
-// the marked points of the first 24 steps of a launch: which wave arrives last at each barrier (= the critical chain).
-#ifdef CAGYM_WAVETRACE
-#define CAGYM_WT_STEPS 24
-#define CAGYM_WT_POINTS 16
-__device__ int g_wt_wg = 7;  // the traced workgroup (cagym_debug_wavetrace_select)
-__device__ unsigned long long g_wavetrace[CAGYM_WT_STEPS * CAGYM_WT_POINTS * 8];
-#define WAVETRACE(t, point)                                                                                           \
-    do {                                                                                                              \
-        if ((threadIdx.x & 63) == 0 && (int)blockIdx.x == g_wt_wg && (t) < CAGYM_WT_STEPS)                             \
-            g_wavetrace[((t) * CAGYM_WT_POINTS + (point)) * 8 + (threadIdx.x >> 6)] = __builtin_amdgcn_s_memtime();   \
-    } while (0)
-#else
-#define WAVETRACE(t, point) do { } while (0)
-#endif
-
-// Static instruction accounting (-DCAGYM_PMARK, tools/isa_phases.py): named comments in the ISA at the phase boundaries
-#ifdef CAGYM_PMARK
-#define PMARK(name) asm volatile("; PMARK " name)
-#else
-#define PMARK(name) do { } while (0)
-#endif
+#include "cagym_spin.h"   // lds_wait_ge: the bounded intra-workgroup wait
+#include "cagym_trace.h"  // STAMP / WGTRACE / WAVETRACE / PMARK: diagnostic hooks, empty in the shipped library
 
 #ifndef CAGYM_GW10
 #define CAGYM_GW10 8  // lanes per ORCA LP group when M <= 10 (nn <= 9 half-planes)
 #endif
 
 __host__ __device__ inline size_t a16(size_t x) { return (x + 15) & ~(size_t)15; }
+
+// Issue priorities.  A workgroup whose worlds needed linearProgram3 in the previous step is in a crowd and stays there for many
+// steps: its step is the long one and the launch ends with the slowest workgroup, so its waves take issue priority over the
+// co-resident workgroups (which have slack).  Inside a workgroup the observation rows are off the critical chain: their waves
+// run at priority 0, the chain (linear programs, S1, pair phases) at 1.  (-DCAGYM_NO_LAG_PRIORITY: A/B switch, 20-step launch 264 -> 233 us.)
+__device__ __forceinline__ void prio_chain3(bool lagging) {
+#ifndef CAGYM_NO_LAG_PRIORITY
+    if (lagging) __builtin_amdgcn_s_setprio(3);
+    else __builtin_amdgcn_s_setprio(1);
+#endif
+}
+__device__ __forceinline__ void prio_rows3() {
+#ifndef CAGYM_NO_LAG_PRIORITY
+    __builtin_amdgcn_s_setprio(0);
+#endif
+}
 // LP group geometry of a specialisation (compile-time M = MT, 0 = run-time M): lanes per group, "more than GW + 1 half-planes
-// possible", and the group's scratch in units of GW float4 (orca_lp_upfront: 2 NL - 1 entries, NL = GW + 1 or 2 GW lines;
-// the OBST instantiation's orca_lp_group_n: 4 GW)
+// possible", and the group's scratch in units of GW float4 (2 GW projected lines; the OBST instantiation's orca_lp_group_n: 4 GW)
 __host__ __device__ constexpr int cagym_gw3(int MT) { return MT > 0 && MT <= 5 ? 4 : (MT > 0 && MT <= 10 ? CAGYM_GW10 : 16); }
 __host__ __device__ constexpr bool cagym_two3(int MT) { return !(MT > 0 && MT - 1 <= cagym_gw3(MT) + 1); }
-#ifdef CAGYM_LP_UPFRONT
-__host__ __device__ constexpr int cagym_lpl3(int MT, bool obst) { return obst ? 4 : (cagym_two3(MT) ? 4 : 3); }
-#else
 __host__ __device__ constexpr int cagym_lpl3(int MT, bool obst) { return obst ? 4 : 2; }
-#endif
 __host__ __device__ inline int cagym_mp(int M) { return (M + 3) & ~3; }
 
 // AS = agent slots per workgroup (worlds per workgroup x M, rounded up to 4); 64 when a full wave is used
@@ -216,17 +156,10 @@ struct Lds3 {
 
 // The ORCA neighbour keys are only alive between phase A (pair lanes write them) and phase B (the half-plane lanes rank with them); the
 // LP scratch only in phase C.  The free-space kernels therefore keep both in the same LDS bytes (M = 20: 43.5 -> 37.1 KB, a fourth
-// workgroup per CU); the OBST kernels borrow the scratch for their obstacle-neighbour lists in phase A and keep them apart, and so does the
-// -DCAGYM_LP_UPFRONT alternative (its LP groups rank inside phase C).
+// workgroup per CU); the OBST kernels borrow the scratch for their obstacle-neighbour lists in phase A and keep them apart.
 // Only where it buys a workgroup (two half-planes per LP lane: M = 20 and the run-time-M kernels): the M <= 10 kernels sit exactly at 128
 // VGPRs and the three extra stores per step cost them a spill.
-__host__ __device__ constexpr bool cagym_dsq_aliased(bool obst, int MT) {
-#ifdef CAGYM_LP_UPFRONT
-    return false;
-#else
-    return !obst && cagym_two3(MT);
-#endif
-}
+__host__ __device__ constexpr bool cagym_dsq_aliased(bool obst, int MT) { return !obst && cagym_two3(MT); }
 __host__ __device__ inline size_t cagym_lds3_head(int AS) {
     return (size_t)20 * AS * 8 + AS * 8 + (size_t)6 * AS * 4 + 96 * 4 + 16 * 4 + (size_t)2 * AS * 8 + (size_t)3 * AS * 4;
 }
@@ -438,12 +371,7 @@ __device__ inline void obstacle_lines_phase3(const CagymDev& D, const Lds3& W, i
     uint8_t* perm = reinterpret_cast<uint8_t*>(todo + ko * AS);  // [ko][AS] candidate at each rank
     uint32_t* cov = W.cov;                               // [ko][AS] bit s of entry (rank r, ego): line s covers candidate r
     const float inv_tho = 1.0f / 5.0f;
-#ifdef CAGYM_STAMPS  // sub-step shares (slots 0, 9, 10, 11; they are part of phase A's slot as well)
-    unsigned long long ob_prev = __builtin_amdgcn_s_memtime();
-#define OBSTAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) { unsigned long long _t = __builtin_amdgcn_s_memtime(); g_stamps[i] += _t - ob_prev; ob_prev = _t; } } while (0)
-#else
-#define OBSTAMP(i) do { } while (0)
-#endif
+    OBSTAMP_BEGIN();
     for (int q = tid; q < nagents * Kobs; q += NTT) {
         const int a = q / Kobs, r = q - a * Kobs;
         if (!W.trvo[a]) continue;
@@ -501,9 +429,7 @@ __device__ inline void obstacle_lines_phase3(const CagymDev& D, const Lds3& W, i
     WGTRACE(34);
     OBSTAMP(9);
     const int ntodo = W.flag[5], nmax = W.flag[6];
-#ifdef CAGYM_WGTRACE
-    if (threadIdx.x == 0 && blockIdx.x < CAGYM_WGTRACE_MAXWG) g_wgtrace[blockIdx.x * CAGYM_WGTRACE_W + 37] = (unsigned long long)(ntodo | (nmax << 16));
-#endif
+    WGTRACE_VALUE(37, ntodo | (nmax << 16));
     for (int q = tid; q < ntodo; q += NTT) {
         const int a = todo[q] >> 8, i = todo[q] & 255;
         const int n = W.nobl[a];
@@ -673,10 +599,9 @@ __device__ __forceinline__ int neighbour_rank3(const Lds3& W, int a, int sl, flo
 }
 
 // ---- phase B body: ORCA half-planes of one unordered pair, ranked into both egos' nearest-first line lists -----------------
-// LAZY (free-space kernels): the half-planes are stored UNSORTED, row = the neighbour's slot with the ego's own slot skipped; the
-// LP group of an ego that turns out busy ranks them (lp_rank_lines3) - two thirds of the egos never need their lines, and
-// the two rank loops per pair lane were the largest part of this phase.  !LAZY (OBST kernels): ranked here, as in round 2.
-template <int MT, bool LAZY>
+// (Round 3 measured storing them unsorted and letting the LP group of a busy ego rank them - "lazy ranking", together with the
+// all-linearProgram1-results-up-front solver: slower as a pair; tools/lp_upfront/ holds both and the numbers.)
+template <int MT>
 __device__ __forceinline__ void half_planes3(const CagymDev& D, const Lds3& W, int p, int M, int MP, int AS, int ko) {
     const UPair q = upair_of<MT>(p, M);
     const int n = W.wn[q.wl];
@@ -694,46 +619,17 @@ __device__ __forceinline__ void half_planes3(const CagymDev& D, const Lds3& W, i
         const float4 ln = make_float4(vax + c * g.ux, vay + c * g.uy, g.zx, g.zy);
         const float2 s0 = W.lpc[a];
         if (detf(ln.z, ln.w, ln.x - s0.x, ln.y - s0.y) > 0.0f) W.busy[a] = 1;
-        if (LAZY) {
-            W.sorted[(q.j < q.i ? q.j : q.j - 1) * AS + a] = ln;
-        } else {
-            const int rank = neighbour_rank3<MT>(W, a, q.j, g.d2, MP);
-            if (rank < D.maxnb) W.sorted[(ko + rank) * AS + a] = ln;
-        }
+        const int rank = neighbour_rank3<MT>(W, a, q.j, g.d2, MP);
+        if (rank < D.maxnb) W.sorted[(ko + rank) * AS + a] = ln;
     }
     if (on_b) {
         const float c = W.tcoop[b];
         const float4 ln = make_float4((float)W.tvx[b] - c * g.ux, (float)W.tvy[b] - c * g.uy, -g.zx, -g.zy);
         const float2 s0 = W.lpc[b];
         if (detf(ln.z, ln.w, ln.x - s0.x, ln.y - s0.y) > 0.0f) W.busy[b] = 1;
-        if (LAZY) {
-            W.sorted[(q.i < q.j ? q.i : q.i - 1) * AS + b] = ln;
-        } else {
-            const int rank = neighbour_rank3<MT>(W, b, q.i, g.d2, MP);
-            if (rank < D.maxnb) W.sorted[(ko + rank) * AS + b] = ln;
-        }
+        const int rank = neighbour_rank3<MT>(W, b, q.i, g.d2, MP);
+        if (rank < D.maxnb) W.sorted[(ko + rank) * AS + b] = ln;
     }
-}
-
-// Lazy ranking (free-space kernels): the LP group of busy ego `a` (slot sl of a world of nw agents) turns its column of
-// unsorted half-planes (row q <-> neighbour slot q < sl ? q : q + 1) into nearest-first order IN PLACE: lane j takes the
-// candidates q = j and q = j + GW, counts each one's rank in the ego's row of squared distances (Agent::insertAgentNeighbor's
-// order: nearer first, ties by lower index) and stores it to row `rank` when that is below nn = min(nw - 1, maxNeighbors).
-// One wave: its LDS operations complete in program order, so every candidate is read before any row is overwritten.
-template <int MT, int GW>
-__device__ __forceinline__ void lp_rank_lines3(const Lds3& W, int a, int sl, int nw, int nn, int j, int M, int MP, int AS) {
-    const int q0 = j, q1 = j + GW;
-    const int o0 = q0 < sl ? q0 : q0 + 1, o1 = q1 < sl ? q1 : q1 + 1;
-    const bool e0 = q0 < M - 1 && o0 < nw, e1 = q1 < M - 1 && o1 < nw;
-    // (clamped addresses instead of conditional loads: a lane without a candidate reads row 0 and never uses it)
-    const float4 c0 = W.sorted[(e0 ? q0 : 0) * AS + a], c1 = W.sorted[(e1 ? q1 : 0) * AS + a];
-    const float d0 = __uint_as_float(W.dsq[a * MP + (e0 ? o0 : 0)].y), d1 = __uint_as_float(W.dsq[a * MP + (e1 ? o1 : 0)].y);
-    const int r0 = neighbour_rank3<MT>(W, a, o0, d0, MP);
-    int r1 = 0;
-    if (__ballot(e1) != 0ull) r1 = neighbour_rank3<MT>(W, a, o1, d1, MP);
-    asm volatile("" ::: "memory");  // all reads of the column stay ahead of its rewriting
-    if (e0 && r0 < nn) W.sorted[r0 * AS + a] = c0;
-    if (e1 && r1 < nn) W.sorted[r1 * AS + a] = c1;
 }
 
 // ---- one 64-row chunk of the OtherAgentsStates table (sensors/OtherAgentsStatesSensor.py:11-77), straight to HBM ----------
@@ -912,7 +808,7 @@ __device__ __forceinline__ void laser_scan3(const CagymDev& D, const Lds3& W, fl
             if (finished_one) __hip_atomic_fetch_add(&W.flag[8], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             c = __hip_atomic_fetch_add(&W.flag[7], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-        c = __builtin_amdgcn_readfirstlane(c);
+        c = __builtin_amdgcn_readlane(c, 0);  // lane 0's claim whatever the loop's shape made of the exec mask (not "the first active lane")
         if (c >= npass) break;
         finished_one = true;
         const int a = c * 4 + (lane >> 4), b = lane & 15;
@@ -966,17 +862,16 @@ __device__ __forceinline__ void laser_scan3(const CagymDev& D, const Lds3& W, fl
         cnt[c] = (uint8_t)__popcll(m);  // (every lane stores the same byte: no branch)
     }
     WGTRACE_W1(30);
-    // every pass was claimed by some wave that is running it now (bounded wait; nobody waits for a wave that never calls)
-    while (__hip_atomic_load(&W.flag[8], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < npass) __builtin_amdgcn_s_sleep(1);
+    // every pass was claimed by some wave that is running it now (nobody waits for a wave that never calls); the wait is bounded all
+    // the same (cagym_spin.h): a count that cannot arrive becomes CAGYM_E_DEVICE at the next entry point, not a hung GPU
+    if (!lds_wait_ge(&W.flag[8], npass)) *D.dev_status = CAGYM_DEVERR_LASER_WAIT;
     int n = 0;
     for (int q = 0; q < npass; q++) n += cnt[q];
-#ifdef CAGYM_WGTRACE
-    if (threadIdx.x == 64 && blockIdx.x < CAGYM_WGTRACE_MAXWG) g_wgtrace[blockIdx.x * CAGYM_WGTRACE_W + 32] = (unsigned long long)n;
-#endif
+    WGTRACE_W1_VALUE(32, n);
     for (;;) {
         int r = 0;
         if (lane == 0) r = __hip_atomic_fetch_add(&W.flag[10], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        r = __builtin_amdgcn_readfirstlane(r);
+        r = __builtin_amdgcn_readlane(r, 0);
         if (r * CAGYM_WAVE >= n) break;
         int i = r * CAGYM_WAVE + lane;  // index into the concatenation of the passes' lists
         if (i < n) {
@@ -1010,7 +905,7 @@ __device__ __forceinline__ void observation_chunks3(const CagymDev& D, const Lds
     for (;;) {
         int c = 0;
         if (lane == 0) c = __hip_atomic_fetch_add(&W.flag[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        c = __builtin_amdgcn_readfirstlane(c);
+        c = __builtin_amdgcn_readlane(c, 0);
         if (c > nck) break;
         if (c < nck) {
             if (o.obs_oas) oas_row3(W, o.obs_oas, c * CAGYM_WAVE + lane, npairs, M, MP, K, wpw, worlds_valid, inv_m);
@@ -1048,11 +943,6 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
     const int AS = cagym_as(M, WPWT);
     const int ko = OBST ? D.ko : 0;  // 2 * Kobs: an agent outside a rectangle sees at most 2 of its edges from their right side
     constexpr int LPL = cagym_lpl3(MT, OBST);
-#ifdef CAGYM_LP_UPFRONT  // measured alternative (cagym_orca.h: orca_lp_upfront): lazy ranking + all linearProgram1 results up front
-    constexpr bool LAZY_RANK = true;
-#else
-    constexpr bool LAZY_RANK = false;
-#endif
     const Lds3 W = carve_lds3(smem, M, AS, NT, ko, LPL, OBST, MT);
     const bool dsq_shared = OBST ? cagym_obst_alias(M, AS, NT, ko, LPL) : cagym_dsq_aliased(false, MT);  // the neighbour keys live in the LP scratch
     LaneCtx C = make_ctx2(D, M, WPWT ? WPWT : CAGYM_WAVE / M);
@@ -1113,7 +1003,7 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
             for (int p = tid; p < nup; p += NT) pair_distances3<MT, false>(D, W, p, M, MP);
             __syncthreads();
             WGTRACE1(23);
-            for (int p = tid; p < nup; p += NT) half_planes3<MT, LAZY_RANK && !OBST>(D, W, p, M, MP, AS, ko);
+            for (int p = tid; p < nup; p += NT) half_planes3<MT>(D, W, p, M, MP, AS, ko);
         }
         __syncthreads();
     }
@@ -1133,16 +1023,8 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
         const size_t aidx = (size_t)(unsigned)aidx32;
         const CagymOut o_prev = out_slice3(out, t > 0 ? t - 1 : 0, (size_t)D.N, NM, M);  // rows of step t-1 (used when t > 0)
         const CagymOut o = out_slice3(out, t, (size_t)D.N, NM, M);
-#ifndef CAGYM_NO_LAG_PRIORITY
-        // A workgroup whose worlds needed linearProgram3 in the previous step is in a crowd and stays there for many
-        // steps: its step is the long one and the launch ends with the slowest workgroup, so its waves take issue
-        // priority over the co-resident workgroups (which have slack).
-        // Inside a workgroup the observation rows are off the critical chain: their waves run at priority 0, the chain
-        // (linear programs, S1, pair phases) at 1.
-        const bool lagging = __builtin_amdgcn_readfirstlane(W.flag[4]) != 0;
-        if (lagging) __builtin_amdgcn_s_setprio(3);
-        else __builtin_amdgcn_s_setprio(1);
-#endif
+        const bool lagging = __builtin_amdgcn_readfirstlane(W.flag[4]) != 0;  // some ego needed linearProgram3 in the previous step
+        prio_chain3(lagging);
         WAVETRACE(t, 0);
         PMARK("C_begin");
         // ---- phase C: linearProgram2/3 of every busy ego on a GW-lane group (first waves) ------------------------------
@@ -1163,9 +1045,7 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
             bool worked = false;
             STAMP(8);  // busy list
             WAVETRACE(t, 1);
-#ifdef CAGYM_STAMPS
-            int dbg[3] = {0, 0, 0};
-#endif
+            LPCOUNT_DBG_DECL();
             PMARK("C_lp_loop");
             // (cfg4: nearly every ego among rectangles is busy - median 35 of a workgroup's 36 RVO agents - so 70 % of the workgroups run
             // a second round of groups for a handful of egos.  Groups of FOUR lanes with four half-planes per lane - one round for up
@@ -1192,33 +1072,13 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
                         else
                             orca_lp_group_n<GW, 2>(W.sorted, W.lp3 + LPL * (tid & ~(GW - 1)), a, j, nol, nn, ko, rad, pv.x, pv.y, vx, vy, AS, &W.flag[3]);
                     } else {
-#ifdef CAGYM_LP_UPFRONT
-                        // the ego's unsorted half-planes -> nearest-first (lazily: only busy egos get here), then all
-                        // linearProgram1 results up front and the find-first-set walk (cagym_orca.h)
-                        lp_rank_lines3<MT, GW>(W, a, a - wl * M, n, nn, j, M, MP, AS);
-                        const float2 s0 = W.lpc[a];
-                        orca_lp_upfront<GW, NL>(W.sorted + a, AS, W.lp3 + LPL * (tid & ~(GW - 1)), j, nn, rad, pv.x, pv.y, s0.x, s0.y, vx, vy, &W.flag[3]);
-#else
-#ifdef CAGYM_WAVETRACE
-                        orca_lp_group<GW, TWO, (MT > 0 ? MT - 1 : 0)>(W.sorted, W.lp3 + LPL * (tid & ~(GW - 1)), a, j, nn, rad, pv.x, pv.y, vx, vy, AS, &W.flag[3], nullptr,
-                                                                  ((int)blockIdx.x == g_wt_wg && t < CAGYM_WT_STEPS && base == 0) ? g_wavetrace + (size_t)t * CAGYM_WT_POINTS * 8 : nullptr);
-#else
-                        orca_lp_group<GW, TWO, (MT > 0 ? MT - 1 : 0)>(W.sorted, W.lp3 + LPL * (tid & ~(GW - 1)), a, j, nn, rad, pv.x, pv.y, vx, vy, AS, &W.flag[3]);
-#endif
-#endif
+                        orca_lp_group<GW, TWO, (MT > 0 ? MT - 1 : 0)>(W.sorted, W.lp3 + LPL * (tid & ~(GW - 1)), a, j, nn, rad, pv.x, pv.y, vx, vy, AS, &W.flag[3],
+                                                                      LPCOUNT_DBG(), LPWT_ROWS(t, base));
                     }
                     if (j == 0) W.lpc[a] = make_float2(vx, vy);
                 }
             }
-#ifdef CAGYM_STAMPS
-            if (wave == 0) {  // lockstep trip counts of wave 0: the longest group sets the wave's time
-                int m0 = dbg[0], m1 = dbg[1], m2 = dbg[2];
-                for (int off = 32; off; off >>= 1) {
-                    m0 = max(m0, __shfl_xor(m0, off)); m1 = max(m1, __shfl_xor(m1, off)); m2 = max(m2, __shfl_xor(m2, off));
-                }
-                if (tid == 0 && blockIdx.x == 0) { g_stamps[12] += m0; g_stamps[13] += m1; g_stamps[14] += m2; g_stamps[15] += cnt; }
-            }
-#endif
+            LPCOUNT_FOLD(wave, tid, cnt);  // (diagnostic) lockstep trip counts of wave 0: the longest group sets the wave's time
             WAVETRACE(t, 2);
             PMARK("C_lp_done");
             // a wave that solved programs publishes them: LDS operations of one wave complete in order, the release
@@ -1239,10 +1099,8 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
         bool moved = false;
         const bool s1_lane = agent_lane && C.valid && C.active;
         if (wave == 0) {
-            if (lp_waves > 0) {  // wait for the other LP waves (bounded: every LP wave increments exactly once per step)
-                while (__hip_atomic_load(&W.flag[2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < lp_waves)
-                    __builtin_amdgcn_s_sleep(1);
-            }
+            // wait for the other LP waves (every LP wave increments exactly once per step; bounded all the same, cagym_spin.h)
+            if (lp_waves > 0 && !lds_wait_ge(&W.flag[2], lp_waves)) *D.dev_status = CAGYM_DEVERR_LP_WAIT;
             STAMP(2);
             WAVETRACE(t, 3);
             PMARK("D_s1_begin");
@@ -1291,15 +1149,10 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
             STAMP(3);
             WAVETRACE(t, 4);
         } else if (t > 0) {
-#ifndef CAGYM_NO_LAG_PRIORITY
-            __builtin_amdgcn_s_setprio(0);
-#endif
+            prio_rows3();
             PMARK("D_rows_begin");
             observation_chunks3<OBST, (ONE ? 8 : CAGYM_LASER_BATCH_ROLLOUT)>(D, W, o_prev, npairs, M, MP, K, C.wpw, C.worlds_valid, inv_m, ko, AS);
-#ifndef CAGYM_NO_LAG_PRIORITY
-            if (lagging) __builtin_amdgcn_s_setprio(3);
-            else __builtin_amdgcn_s_setprio(1);
-#endif
+            prio_chain3(lagging);
             WAVETRACE(t, 4);
         }
         PMARK("D_end_barrierX");
@@ -1437,11 +1290,11 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
             }
             PMARK("B_s2_end");
             // a last partial round of at most one wave of pairs is wave 0's (it is done with S2 before the others finish)
-            if (any_rvo && more && tail_pairs <= CAGYM_WAVE && tid < tail_pairs) half_planes3<MT, LAZY_RANK && !OBST>(D, W, full_pairs + tid, M, MP, AS, ko);
+            if (any_rvo && more && tail_pairs <= CAGYM_WAVE && tid < tail_pairs) half_planes3<MT>(D, W, full_pairs + tid, M, MP, AS, ko);
         } else if (any_rvo && more) {
             const int lim = tail_pairs <= CAGYM_WAVE ? full_pairs : nup;
             PMARK("B_hp_begin");
-            for (int p = tid - CAGYM_WAVE; p < lim; p += NT - CAGYM_WAVE) half_planes3<MT, LAZY_RANK && !OBST>(D, W, p, M, MP, AS, ko);
+            for (int p = tid - CAGYM_WAVE; p < lim; p += NT - CAGYM_WAVE) half_planes3<MT>(D, W, p, M, MP, AS, ko);
         }
         if (OBST && ONE && o.laserscan) {
             // the one-step launch (every step of the VecEnv path; the roll-out kernels sit at their register limit and keep the scan
@@ -1479,7 +1332,7 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
             }
             __syncthreads();
             if (any_rvo && more)
-                for (int p = tid; p < nup; p += NT) half_planes3<MT, LAZY_RANK && !OBST>(D, W, p, M, MP, AS, ko);
+                for (int p = tid; p < nup; p += NT) half_planes3<MT>(D, W, p, M, MP, AS, ko);
             __syncthreads();
         }
         PMARK("step_end");
@@ -1516,17 +1369,12 @@ template <int NT, int MT, int WPWT, bool AUTO_RESET, bool OBST>
 __global__ void __launch_bounds__(NT, OBST ? 2 : cagym_min_waves3(NT, MT)) k_rollout3(CagymDev D, int n_steps, CagymOut out, int any_rvo) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     WGTRACE(0);
-#ifdef CAGYM_WGTRACE
-    if (threadIdx.x == 0 && blockIdx.x < CAGYM_WGTRACE_MAXWG) g_wgtrace[blockIdx.x * CAGYM_WGTRACE_W + 39] = 0;
-#endif
+    WGTRACE_VALUE(39, 0);
     // the OBST body is too large for the inliner's taste; called out of line it would get the device struct through scratch
     if (OBST) { [[clang::always_inline]] run_steps3<NT, MT, WPWT, AUTO_RESET, OBST>(D, smem, nullptr, out, n_steps, any_rvo != 0); }
     else run_steps3<NT, MT, WPWT, AUTO_RESET, OBST>(D, smem, nullptr, out, n_steps, any_rvo != 0);
-#ifdef CAGYM_WGTRACE
     WGTRACE(38);
-    if (threadIdx.x == 0 && blockIdx.x < CAGYM_WGTRACE_MAXWG)
-        g_wgtrace[blockIdx.x * CAGYM_WGTRACE_W + 39] |= __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) & 15u;  // HW_REG_XCC_ID
-#endif
+    WGTRACE_XCC();
 }
 
 // one step with external actions; the output buffers are NOT sliced (out_slice3 with t = 0 is the identity)
@@ -1534,9 +1382,7 @@ template <int NT, int MT, int WPWT, bool AUTO_RESET, bool OBST>
 __global__ void __launch_bounds__(NT, OBST ? 2 : cagym_min_waves3(NT, MT)) k_step3(CagymDev D, const float* ext, CagymOut out, int any_rvo) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     WGTRACE(0);
-#ifdef CAGYM_WGTRACE
-    if (threadIdx.x == 0 && blockIdx.x < CAGYM_WGTRACE_MAXWG) g_wgtrace[blockIdx.x * CAGYM_WGTRACE_W + 39] = 0;
-#endif
+    WGTRACE_VALUE(39, 0);
     if (OBST) { [[clang::always_inline]] run_steps3<NT, MT, WPWT, AUTO_RESET, OBST, true>(D, smem, ext, out, 1, any_rvo != 0); }
     else run_steps3<NT, MT, WPWT, AUTO_RESET, OBST, true>(D, smem, ext, out, 1, any_rvo != 0);
     WGTRACE(38);

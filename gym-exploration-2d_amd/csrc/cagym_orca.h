@@ -10,6 +10,7 @@
 // data-dependent indexing of linearProgram1/3 costs no scratch memory.
 #pragma once
 #include "cagym_device.h"
+#include "cagym_trace.h"
 
 #define RVO_EPS 0.00001f
 
@@ -392,25 +393,13 @@ __device__ __forceinline__ bool orca_project(const float4 li, const float4 lj, f
 // (lane 0's second line) is only ever TESTED, never clipped against or projected.  TWO = true serves nn <= 2 GW lines
 // (maxNeighbors follows Config.MAX_NUM_AGENTS_IN_ENVIRONMENT, RVOPolicy.py:15: 19 lines with 20 agents).  P: private
 // scratch of 2 GW projected lines.
-#ifdef CAGYM_STAMPS
-#define LPCOUNT(x) ((x)++)
-#else
-#define LPCOUNT(x) do { } while (0)
-#endif
 // ROWS: compile-time row count of the ego's column (M - 1) or 0: lanes j < ROWS load their first half-plane without
 // waiting for nn (a stale row is never looked at: every use is guarded by j < nn).
 template <int GW, bool TWO, int ROWS = 0>
 __device__ inline void orca_lp_group(const float4* L, float4* P, int a, int j, int nn, float radius, float ox, float oy,
                                      float& rx, float& ry, int stride, int* lp3_flag = nullptr, int* dbg = nullptr,
                                      unsigned long long* wt = nullptr) {
-#ifdef CAGYM_STAMPS
-    int c_lp2 = 0, c_lp3o = 0, c_lp3i = 0;
-#endif
-#ifdef CAGYM_WAVETRACE
-#define LPWT(k) do { if (wt && (threadIdx.x & 63) == 0) wt[(k) * 8 + (threadIdx.x >> 6)] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define LPWT(k) do { } while (0)
-#endif
+    LPCOUNT_DECL();
     const int gbase = (threadIdx.x & 63) & ~(GW - 1);
     const uint64_t gbits = (1ull << GW) - 1ull;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -428,7 +417,7 @@ __device__ inline void orca_lp_group(const float4* L, float4* P, int a, int j, i
     // lines the one line beyond the lanes - the farthest neighbour - computes its chord in the rare round that needs it)
     const float2 c0 = orca_chord(l0, radius), c1 = TWO ? orca_chord(l1, radius) : make_float2(0.f, 0.f);
     asm volatile("" :: "v"(l0.x), "v"(rx));
-    LPWT(13);
+    LPWT(wt, 13);
     // linearProgram2.  The reference walks the lines in order and projects onto each violated one; between two
     // projections the result does not change, so "the next violated line at or after cur" is one parallel test
     // (lane j tests its half-planes) + a find-first-set.  The groups of a wave then run linearProgram1 in lockstep,
@@ -461,7 +450,7 @@ __device__ inline void orca_lp_group(const float4* L, float4* P, int a, int j, i
     // linearProgram3 (rare).  Same scan-and-jump: the next line at or after `cur` that is violated by more than
     // `distance`, then linearProgram2 (directionOpt) over the projected lines, again by scan-and-jump.
     float distance = 0.0f;
-    LPWT(14);
+    LPWT(wt, 14);
     if (lp3_flag && fail < nn && j == 0) *lp3_flag = 1;  // this workgroup is in a crowd: its step is the long one
     for (int cur = fail; cur < nn;) {
         const bool w0 = j >= cur && j < nn && detf(l0.z, l0.w, l0.x - rx, l0.y - ry) > distance;
@@ -509,209 +498,9 @@ __device__ inline void orca_lp_group(const float4* L, float4* P, int a, int j, i
         else { rx = qx; ry = qy; }
         distance = detf(li.z, li.w, li.x - rx, li.y - ry);
     }
-#ifdef CAGYM_STAMPS
-    if (dbg) { dbg[0] = c_lp2; dbg[1] = c_lp3o; dbg[2] = c_lp3i; }
-#endif
+    LPCOUNT_OUT(dbg);
 }
 
-
-// ---- linearProgram2 + linearProgram3 of one ego on a GW-lane group: ALL linearProgram1 results up front ---------------------
-// MEASURED ALTERNATIVE, NOT THE DEFAULT (-DCAGYM_LP_UPFRONT selects it together with the lazy ranking of cagym_kernels3.h;
-// bit-identical to the scan-and-jump solver above: same GPU tests).  Round 3 built it as the review asked and measured it:
-// 4096 x 10, 512-step launches 4.08 -> 5.44 ms, wave-VALU instructions per workgroup-step 3418 -> 4076 (ORCA part 1733 ->
-// 2383, profiles/r3/valu_breakdown_*.txt), first program of an LP wave 3100 -> 8000 cycles (profiles/r3/wave_trace_lp_upfront.txt).
-// Why: under four co-resident workgroups a wave issues one VALU instruction per ~12 cycles whatever its ILP, so a chain costs
-// its INSTRUCTION COUNT, and computing R_i for all 9 lines (36 clips with a correctly rounded division each, ~500 instructions
-// per pass, one more pass per linearProgram3 outer iteration for the whole wave) is more instructions than the 2.7 rounds
-// x 70 the median ego needs.  Kept for the record and for A/B.
-// (CPU proof of equivalence with the sequential programs, bit for bit on 3 million half-plane sets:
-// tools/lp_upfront_check.c.)  linearProgram1(i) - "the optimum on line i subject to the lines before it" - does not
-// depend on the running result, only on line i, the lines before it and the optimisation velocity.  The scan-and-jump
-// solver of round 2 evaluated it when the walk reached line i: one lockstep round of ~1000 cycles of DEPENDENT work
-// per projection (fetch the line, sqrt, one division per lane, two DPP reductions, a ballot), 2.7 rounds for the median
-// ego and three times that in a crowd - the chain that ended every launch.  Here R_i and "infeasible at i" are computed
-// for ALL lines first: lane j owns lines hi = n-1-j and lo = j (n-1 clips per lane whatever j is: the triangle of (line, earlier
-// line) pairs is dealt evenly), each lane folds its own min / max in registers - independent, pipelined divisions, no
-// cross-lane operation at all - and publishes (R_i, feasible_i) in the group's scratch.  linearProgram2's sequential part
-// is then: every lane tests its two lines against the current point, a ballot turns that into a bit mask over line indices,
-// find-first-set picks the next violated line, one LDS read fetches its R_i.  linearProgram3 keeps its outer scan; each
-// inner program (directionOpt, projected lines with holes) runs through the SAME solver body: the function is a small
-// state machine whose loop contains the solver once.
-// Line set: L[k * stride] for k < n (the ego's column of the sorted half-planes).  S: group-private scratch of 2 NL - 1
-// float4 (NL = compile-time bound on n): S[0 .. NL-1] = (R.x, R.y, feasible, -) per line, S[NL ..] = projected lines.
-// (sx, sy) = linearProgram2's start (the optimisation velocity clipped to the disc: W.lpc).  All lanes of a group pass the same
-// (n, radius, ox, oy, sx, sy); groups of one wave may differ.
-template <int GW>
-__device__ __forceinline__ uint32_t orca_line_mask(bool v_lo, bool v_hi, int nl, int gbase) {
-    // lane j's `lo` bit belongs to line j, its `hi` bit to line nl-1-j: mask over line indices of the group
-    const uint32_t gbits = (GW >= 32) ? 0xffffffffu : ((1u << GW) - 1u);
-    const uint32_t blo = (uint32_t)(__ballot(v_lo) >> gbase) & gbits;
-    const uint32_t bhi = (uint32_t)(__ballot(v_hi) >> gbase) & gbits;
-    return blo | (__brev(bhi) >> ((32 - nl) & 31));
-}
-// one clip of linearProgram1: line li against the earlier line lk, folded into the lane's own (tLeft, tRight, infeasible)
-__device__ __forceinline__ void orca_clip_acc(const float4 li, const float4 lk, bool take, float& tl, float& tr, bool& bad) {
-    const float den = detf(li.z, li.w, lk.z, lk.w);
-    const float num = detf(lk.z, lk.w, li.x - lk.x, li.y - lk.y);
-    const bool par = fabsf(den) <= RVO_EPS;
-    const float t = num / den;
-    if (take) {
-        if (par) bad = bad || (num < 0.0f);
-        else if (den >= 0.0f) tr = fminf(tr, t);
-        else tl = fmaxf(tl, t);
-    }
-}
-// the rest of linearProgram1 once the interval is known
-__device__ __forceinline__ float2 orca_lp1_point(const float4 l, float tl, float tr, float ox, float oy, bool dir_opt) {
-    float t;
-    if (dir_opt) {
-        t = (ox * l.z + oy * l.w > 0.0f) ? tr : tl;
-    } else {
-        t = l.z * (ox - l.x) + l.w * (oy - l.y);
-        if (t < tl) t = tl;
-        else if (t > tr) t = tr;
-    }
-    return make_float2(l.x + t * l.z, l.y + t * l.w);
-}
-#ifndef CAGYM_LP_UNROLL1
-#define CAGYM_LP_UNROLL1
-#define CAGYM_LP_UNROLL2
-#endif
-template <int GW, int NL>
-__device__ inline void orca_lp_upfront(const float4* L, int stride, float4* S, int j, int n, float radius, float ox, float oy,
-                                       float sx, float sy, float& rx, float& ry, int* lp3_flag = nullptr, unsigned long long* wt = nullptr) {
-#ifdef CAGYM_WAVETRACE
-#define LPWT(k) do { if (wt && (threadIdx.x & 63) == 0) wt[(k) * 8 + (threadIdx.x >> 6)] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define LPWT(k) do { } while (0)
-#endif
-    const int gbase = (threadIdx.x & 63) & ~(GW - 1);
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4* PJ = S + NL;
-    // the program being solved: line k = base[k * st], k < nl, existing when bit k of hv
-    const float4* base = L;
-    int st = stride, nl = n;
-    uint32_t hv = 0xffffffffu;
-    float optx = ox, opty = oy, stx = sx, sty = sy;
-    bool dir_opt = false;
-    // linearProgram3's outer state
-    bool active = true, in_lp3 = false;
-    float distance = 0.0f;
-    int cur = 0;
-    float4 li = zero4;
-    rx = sx;
-    ry = sy;
-    LPWT(13);
-    for (int pass = 0;; pass++) {
-        if (pass == 1) LPWT(14);
-        if (__ballot(active) == 0ull) break;  // wave-uniform: every group of the wave is done
-        int fail = nl;
-        float X = stx, Y = sty;
-        if (active) {
-            // ---- own lines and their chords in the disc ---------------------------------------------------------------
-            const int hi = nl - 1 - j, lo = j;
-            const bool hi_ok = j < ((nl + 1) >> 1) && ((hv >> hi) & 1u), lo_ok = j < (nl >> 1) && ((hv >> lo) & 1u);
-            const float4 lh = base[(hi_ok ? hi : 0) * st], ll = base[(lo_ok ? lo : 0) * st];  // (a lane without a line reads row 0: never used)
-            const float doth = lh.x * lh.z + lh.y * lh.w, dotl = ll.x * ll.z + ll.y * ll.w;
-            const float disch = doth * doth + radius * radius - (lh.x * lh.x + lh.y * lh.y);
-            const float discl = dotl * dotl + radius * radius - (ll.x * ll.x + ll.y * ll.y);
-            const float sqh = sqrtf(disch < 0.0f ? 0.0f : disch), sql = sqrtf(discl < 0.0f ? 0.0f : discl);
-            float tlh = -doth - sqh, trh = -doth + sqh, tll = -dotl - sql, trl = -dotl + sql;
-            bool badh = !hi_ok || disch < 0.0f, badl = !lo_ok || discl < 0.0f;
-            // ---- all clips: line hi by the lines 0 .. hi-1, line lo by 0 .. lo-1 -------------------------------------------
-            CAGYM_LP_UNROLL1
-            for (int k = 0; k < NL - 1; k++) {
-                const bool take = hi_ok && k < hi;
-                if (__ballot(take) == 0ull) break;
-                const float4 lk = base[k * st];
-                orca_clip_acc(lh, lk, take && ((hv >> k) & 1u), tlh, trh, badh);
-            }
-            CAGYM_LP_UNROLL2
-            for (int k = 0; k < NL / 2 - 1; k++) {
-                const bool take = lo_ok && k < lo;
-                if (__ballot(take) == 0ull) break;
-                const float4 lk = base[k * st];
-                orca_clip_acc(ll, lk, take && ((hv >> k) & 1u), tll, trl, badl);
-            }
-            const bool feash = !badh && !(tlh > trh), feasl = !badl && !(tll > trl);
-            const float2 Rh = orca_lp1_point(lh, tlh, trh, optx, opty, dir_opt), Rl = orca_lp1_point(ll, tll, trl, optx, opty, dir_opt);
-            if (hi_ok) S[hi] = make_float4(Rh.x, Rh.y, feash ? 1.0f : 0.0f, 0.0f);
-            if (lo_ok) S[lo] = make_float4(Rl.x, Rl.y, feasl ? 1.0f : 0.0f, 0.0f);
-            // ---- the walk of linearProgram2: next violated line after c, by find-first-set ------------------------------------
-            int c = -1;
-            bool done = false;
-            for (;;) {
-                const bool vh = !done && hi_ok && hi > c && detf(lh.z, lh.w, lh.x - X, lh.y - Y) > 0.0f;
-                const bool vl = !done && lo_ok && lo > c && detf(ll.z, ll.w, ll.x - X, ll.y - Y) > 0.0f;
-                const uint32_t m = orca_line_mask<GW>(vl, vh, nl, gbase);
-                if (!done) {
-                    if (m == 0u) {
-                        done = true;
-                    } else {
-                        const int i = __ffs((int)m) - 1;
-                        const float4 e = S[i];  // same wave: the stores above are ordered before this load
-                        if (e.z == 0.0f) { fail = i; done = true; }  // infeasible at line i: the result keeps its value (tempResult)
-                        else { c = i; X = e.x; Y = e.y; }
-                    }
-                }
-                if (__ballot(!done) == 0ull) break;
-            }
-        }
-        // ---- linearProgram3 around it ------------------------------------------------------------------------------------------
-        if (active) {
-            if (!in_lp3) {
-                rx = X;
-                ry = Y;
-                if (fail == n) {
-                    active = false;
-                } else {
-                    in_lp3 = true;
-                    distance = 0.0f;
-                    cur = fail;
-                    if (lp3_flag && j == 0) *lp3_flag = 1;  // this workgroup is in a crowd
-                }
-            } else {
-                if (fail == nl) { rx = X; ry = Y; }  // the inner program was feasible; otherwise the result keeps its value
-                distance = detf(li.z, li.w, li.x - rx, li.y - ry);
-            }
-        }
-        if (active) {  // in linearProgram3: the next ORIGINAL line violated by more than `distance`
-            const int hi0 = n - 1 - j, lo0 = j;
-            const bool h_ok = j < ((n + 1) >> 1), l_ok = j < (n >> 1);
-            const float4 oh = L[(h_ok ? hi0 : 0) * stride], ol = L[(l_ok ? lo0 : 0) * stride];
-            const bool wh = h_ok && hi0 >= cur && detf(oh.z, oh.w, oh.x - rx, oh.y - ry) > distance;
-            const bool wl = l_ok && lo0 >= cur && detf(ol.z, ol.w, ol.x - rx, ol.y - ry) > distance;
-            const uint32_t wm = orca_line_mask<GW>(wl, wh, n, gbase);
-            if (wm == 0u) {
-                active = false;
-            } else {
-                const int i = __ffs((int)wm) - 1;
-                cur = i + 1;
-                li = L[i * stride];
-                // the lines before i projected onto line i (a hole where "parallel, same direction")
-                bool hh = false, hl = false;
-                float4 pj;
-                if (h_ok && hi0 < i) {
-                    hh = orca_project(li, oh, pj);
-                    if (hh) PJ[hi0] = pj;
-                }
-                if (l_ok && lo0 < i) {
-                    hl = orca_project(li, ol, pj);
-                    if (hl) PJ[lo0] = pj;
-                }
-                hv = orca_line_mask<GW>(hl, hh, n, gbase);
-                nl = i;
-                base = PJ;
-                st = 1;
-                optx = -li.w;
-                opty = li.z;
-                dir_opt = true;
-                stx = optx * radius;
-                sty = opty * radius;
-            }
-        }
-    }
-}
 
 // ---- static obstacles in the ORCA solve --------------------------------------------------------------------------------
 // RVOPolicy.find_next_action hands the world's rectangles to its private simulator (policies/RVOPolicy.py:56-57

@@ -13,7 +13,8 @@
  *  - Every call returns 0 or a negative CAGYM_E* code; cagym_last_error() gives the message.
  *    Nothing throws across the ABI.  There is NO CPU fallback: without a HIP device
  *    cagym_create fails with CAGYM_E_NODEVICE.
- *  - A handle is not thread-safe; one handle per GPU.
+ *  - A handle is not thread-safe; one handle per GPU; at most ONE call per handle in flight on the device unless a function
+ *    says otherwise (calls on different streams must be ordered by the caller: several entry points keep cursors on the handle).
  *  - Layout: N worlds x M agent slots, structure-of-arrays, world-major ([N][M]).
  */
 #ifndef CAGYM_H
@@ -27,7 +28,9 @@ extern "C" {
 #define CAGYM_VERSION 111 /* 0.1.1: cagym_config.rvo_max_neighbors, cagym_kernel_name */
 
 enum { CAGYM_OK = 0, CAGYM_E_INVALID = -1, CAGYM_E_NODEVICE = -2, CAGYM_E_HIP = -3, CAGYM_E_NOMEM = -4,
-       CAGYM_E_STATE = -5, CAGYM_E_UNSUPPORTED = -6 };
+       CAGYM_E_STATE = -5, CAGYM_E_UNSUPPORTED = -6,
+       CAGYM_E_DEVICE = -7 /* a kernel of an earlier launch on this handle reported an internal error (a bounded intra-workgroup wait
+                              expired): the handle's device state is void; every later launching call returns this code */ };
 
 /* policy ids: which action map / policy drives an agent (env.py:298-320) */
 enum { CAGYM_POL_STATIC = 0,   /* policies/StaticPolicy.py:9-12            a = (0, 0)                      */

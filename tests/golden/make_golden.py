@@ -27,6 +27,10 @@ sys.path.insert(0, HERE)
 sys.path.insert(0, REPO)
 import ref_harness as rh
 
+# where the archives are written: tests/golden/ itself, or a scratch directory (tests/test_fixture_repro.py regenerates a group
+# there and compares it byte for byte with the committed file)
+OUT = os.environ.get("CAGYM_GOLDEN_OUT") or HERE
+
 rh.install_standins()
 from gym_collision_avoidance.envs.config import Config  # noqa: E402
 
@@ -281,13 +285,31 @@ def save(group, cases):
     for name, c in cases.items():
         for k, v in c.items():
             flat[name + "__" + k] = v
-    path = os.path.join(HERE, group + ".npz")
+    path = os.path.join(OUT, group + ".npz")
     np.savez_compressed(path, **flat)
     print("%-28s %3d cases %8.1f KB" % (group, len(cases), os.path.getsize(path) / 1024))
 
 
 def f32exact(x):
     return np.asarray(x, dtype=np.float32).astype(np.float64)
+
+
+def static_mixes():
+    """Group B on its own (it draws no random numbers): `--static-mixes-only` regenerates just this archive - what
+    tests/test_fixture_repro.py compares byte for byte with the committed file."""
+    U, NC, ST = scen.DYN_UNICYCLE, scen.POLICY_NONCOOP, scen.POLICY_STATIC
+    cases = {}
+    with rh.quiet():
+        P4, P6 = tc.preset_testCases(4), tc.preset_testCases(6)
+    cases["n4_static_odd"] = run_case(P4[6 if len(P4) > 6 else 0], [NC, ST, NC, ST], U, homogeneous=True)
+    cases["n4_static_even"] = run_case(P4[6 if len(P4) > 6 else 0], [ST, NC, ST, NC], U, homogeneous=True)
+    cases["n6_static_mix"] = run_case(P6[0], [NC, NC, ST, NC, ST, NC], U, homogeneous=True)
+    # a static agent parked on a NonCooperative agent's path: collision with static as member i and j
+    blk = np.array([[-3, 0, 3, 0, 1.0, 0.5], [0, 0.2, 5, 5, 1.0, 0.5], [3, 0.1, -3, 0.1, 1.0, 0.4]])
+    cases["n3_static_block_j"] = run_case(blk, [NC, ST, NC], U, homogeneous=True)
+    cases["n3_static_block_i"] = run_case(blk[[1, 0, 2]], [ST, NC, NC], U, homogeneous=True)
+    save("static_mixes", cases)
+    return P4, P6, blk
 
 
 def main():
@@ -314,17 +336,7 @@ def main():
     save("presets_large", cases)
 
     # B. Static / NonCooperative mixes: Q8 (static as pair member j), Q9 (timeout reward), timeouts
-    cases = {}
-    with rh.quiet():
-        P4, P6 = tc.preset_testCases(4), tc.preset_testCases(6)
-    cases["n4_static_odd"] = run_case(P4[6 if len(P4) > 6 else 0], [NC, ST, NC, ST], U, homogeneous=True)
-    cases["n4_static_even"] = run_case(P4[6 if len(P4) > 6 else 0], [ST, NC, ST, NC], U, homogeneous=True)
-    cases["n6_static_mix"] = run_case(P6[0], [NC, NC, ST, NC, ST, NC], U, homogeneous=True)
-    # a static agent parked on a NonCooperative agent's path: collision with static as member i and j
-    blk = np.array([[-3, 0, 3, 0, 1.0, 0.5], [0, 0.2, 5, 5, 1.0, 0.5], [3, 0.1, -3, 0.1, 1.0, 0.4]])
-    cases["n3_static_block_j"] = run_case(blk, [NC, ST, NC], U, homogeneous=True)
-    cases["n3_static_block_i"] = run_case(blk[[1, 0, 2]], [ST, NC, NC], U, homogeneous=True)
-    save("static_mixes", cases)
+    P4, P6, blk = static_mixes()
 
     # A'/B'. the same presets with a seeded perturbation of starts/goals: the exact presets meet at
     # ulp-level knife edges (d == r_i + r_j exactly), where the reference's own masks depend on
@@ -510,7 +522,7 @@ def ig_primitives():
                     nxt[q, k] = r
                     feas[q, k] = True
         out[wname + "__np_next"], out[wname + "__np_feasible"] = nxt, feas
-    path = os.path.join(HERE, "ig_primitives.npz")
+    path = os.path.join(OUT, "ig_primitives.npz")
     np.savez_compressed(path, **out)
     print("%-28s          %8.1f KB" % ("ig_primitives", os.path.getsize(path) / 1024))
 
@@ -550,7 +562,7 @@ def ga3c_states():
             states.append(st)
         out[name + "__agents6"] = w
         out[name + "__states"] = np.array(states)
-    path = os.path.join(HERE, "ga3c_states.npz")
+    path = os.path.join(OUT, "ga3c_states.npz")
     np.savez_compressed(path, **out)
     print("%-28s          %8.1f KB" % ("ga3c_states", os.path.getsize(path) / 1024))
 
@@ -587,7 +599,7 @@ def dmcts_reference(n_seeds=6, n_steps=6):
         out["first_actions"].append(acts)
         out["pos"].append(pos)
     Config.STATES_IN_OBS = list(OBS_KEYS)
-    path = os.path.join(HERE, "ig_dmcts_reference.npz")
+    path = os.path.join(OUT, "ig_dmcts_reference.npz")
     np.savez_compressed(path, **{k: np.array(v, dtype=np.float64) for k, v in out.items()})
     print("%-28s          %8.1f KB" % ("ig_dmcts_reference", os.path.getsize(path) / 1024))
     print(np.array(out["cum_reward"])[:, -1])
@@ -702,7 +714,7 @@ def scenario_statistics(n_worlds=400, n_agents=10):
         for i, a in enumerate(agents):
             rows[w, i] = [a.pos_global_frame[0], a.pos_global_frame[1], a.goal_global_frame[0], a.goal_global_frame[1]]
             noncoop[w, i] = type(a.policy).__name__ == "NonCooperativePolicy"
-    path = os.path.join(HERE, "scenario_stats.npz")
+    path = os.path.join(OUT, "scenario_stats.npz")
     np.savez_compressed(path, rows=rows, noncoop=noncoop)
     print("%-28s          %8.1f KB" % ("scenario_stats", os.path.getsize(path) / 1024))
 
@@ -765,7 +777,7 @@ def adapters():
         rec["traj%d__vel" % i] = np.array([d["pedestrian_state"]["velocity"] for d in tr], dtype=np.float64)
         rec["traj%d__other_pos" % i] = np.array([d["other_agents_pos"] for d in tr], dtype=np.float64)
         rec["traj%d__other_vel" % i] = np.array([d["other_agents_vel"] for d in tr], dtype=np.float64)
-    path = os.path.join(HERE, "adapters.npz")
+    path = os.path.join(OUT, "adapters.npz")
     np.savez_compressed(path, agents6=a6, heading0=heading0, policy_id=pol, coop=np.array([a.cooperation_coef for a in env.agents]),
                         keys=np.array(keys), flat=np.array(flat), n_traj=np.array(len(trajs)), last_time=np.array(last),
                         step_num=np.array([a.step_num for a in env.agents]),
@@ -790,6 +802,8 @@ if __name__ == "__main__":
         rvo_episodes()
     elif "--ga3c-episodes-only" in only:
         ga3c_episodes()
+    elif "--static-mixes-only" in only:
+        static_mixes()
     else:  # the whole recipe, end to end
         main()
         rvo_episodes()

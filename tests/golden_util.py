@@ -211,3 +211,28 @@ def replay(case, make_env, ftol=1e-12, oas_tol=1e-12, laser_tol=1e-12, check=Non
         cmp(t + 1)
     errs["steps_compared"] = errs.get("knife_stop_at", T + 1)
     return errs
+
+
+def laser_audit(scan_a, scan_b, pose_a, pose_b, tol=1e-6, base_margin=1e-9):
+    """LaserScan is index work (sensors/LaserScanSensor.py:27-58 samples Map.world_coordinates_to_map_indices, Map.py:49-59):
+    two backends may only disagree on a beam when the sample that decides it sits on a raster-cell border for the poses they
+    hold.  scan_* [N, M, 16]; pose_* = (px, py, heading) arrays [N, M] of the two backends.  Every beam that differs by more than
+    `tol` is audited: some sample of that beam (or the ego's own cell, which moves the own-disc mask) must lie within
+    `base_margin` + the two backends' pose difference (|dp| + range x |dheading|) of a cell border; a beam that differs without
+    such a border is an index error.  Returns (number of differing beams, list of unexplained (world, agent, beam, distance to
+    the nearest border in cells, margin in cells))."""
+    a, b = np.asarray(scan_a, dtype=np.float64), np.asarray(scan_b, dtype=np.float64)
+    bad = np.argwhere(np.abs(a - b) > tol)
+    unexplained = []
+    rstep, astep = 2 * np.pi / 16, 2 * np.pi / 15
+    for n, m, beam in bad:
+        px, py, h = (float(np.asarray(v)[n, m]) for v in pose_a)
+        qx, qy, qh = (float(np.asarray(v)[n, m]) for v in pose_b)
+        ang = (np.pi if beam == 15 else beam * astep - np.pi) + h
+        rg = np.arange(16) * rstep
+        cells = np.concatenate([10.0 * (px + rg * np.cos(ang)), 10.0 * (py + rg * np.sin(ang)), [10.0 * px, 10.0 * py]])
+        dist = float(np.abs(cells - np.rint(cells)).min())
+        margin = 10.0 * (base_margin + 2.0 * (abs(px - qx) + abs(py - qy)) + 2.0 * 6.0 * abs((h - qh + np.pi) % (2 * np.pi) - np.pi))
+        if dist > margin:
+            unexplained.append((int(n), int(m), int(beam), dist, margin))
+    return len(bad), unexplained

@@ -1,6 +1,6 @@
-/* lp_upfront_check.c -- CPU check of the restructured ORCA linear programs (csrc/cagym_orca.h: orca_lp_upfront) against
+/* lp_upfront_check.c -- CPU check of the restructured ORCA linear programs (tools/lp_upfront/orca_lp_upfront.h) against
  * the oracle's sequential linearProgram2/3 (oracle/cagym_oracle.c: lp2 / lp3), BIT FOR BIT, on random and degenerate
- * half-plane sets.  Test infrastructure only (build: gcc -O2 -ffp-contract=off -o /tmp/lpc tools/lp_upfront_check.c -lm).
+ * half-plane sets.  Test infrastructure only (build: gcc -O2 -ffp-contract=off -o /tmp/lpc tools/lp_upfront/lp_upfront_check.c -lm).
  *
  * The restructuring: linearProgram1(i) depends only on line i, the lines before it and the
  * optimisation velocity - not on the running result - so R_i ("the optimum on line i", or "infeasible at i") is computed
