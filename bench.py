@@ -61,6 +61,11 @@ def parse_args(argv=None):
     ap.add_argument("--per-step-launch", action="store_true", help="one cagym_step_autoreset launch per env step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--halves", type=int, default=1, help="cfg4: split the rank's worlds into this many independent groups, each with its own handle and HIP stream, so that one group's GA3C forward (matrix cores) overlaps another group's env step (vector units); 1 = one group (measured: 0.302 ms with 1, 0.383 with 2, 0.500 with 4 - cagym_ga3c_act costs 78 us for half the worlds, 84 us for all: not kept as default)")
+    ap.add_argument("--cfg4-step", default="fused", choices=["fused", "split", "overlap"],
+                    help="cfg4: fused = cagym_ga3c_act, then cagym_step_autoreset (default; round 4: time-shared LDS, four workgroups per CU); "
+                         "split = cagym_step_begin, cagym_ga3c_act, cagym_step_finish on one stream; overlap = cagym_step_begin on a side stream BESIDE "
+                         "cagym_ga3c_act, then cagym_step_finish.  Bit-identical results (tests/test_split_step.py); measured 0.194 / 0.213 / 0.251 ms per step: "
+                         "side by side on a CU the two kernels halve each other's occupancy and each takes twice as long (profiles/r4/cfg4_overlap*.txt)")
     ap.add_argument("--max-obstacles", type=int, default=10, help="cfg4: rectangles per world are drawn from 2..this (BASELINE: 10); occupancy experiments only")
     ap.add_argument("--graph", action="store_true", help="cfg4: replay the step's launches from one captured HIP graph (measured: 0.311 vs 0.303 ms eager - the step is not launch-bound; profiles/r3/cfg4_graph_vs_eager.txt)")
     ap.add_argument("--pool-factor", type=int, default=8, help="scenario pool size = factor x worlds")
@@ -240,8 +245,16 @@ def main():
         workload = ("%d worlds x %d agents%s: agent 0 GA3C-CADRL (fused LSTM-64 + 3 x FC-256 forward per step), 9 RVO/ORCA agents "
                     "among 2-10 rectangles (obstacle half-planes), LaserScan + OtherAgentsStates on every agent, auto-reset "
                     "(BASELINE configs[3])" % (N, M, " on this rank" if world_size > 1 else ""))
-        launch_mode = "per step: cagym_ga3c_act (device-side selection + state vectors + fused forward, no host sync) + cagym_step_autoreset (laser scan inside)"
-        kernel_name = env.kernel_name(rollout=False, auto_reset=True)
+        split = args.cfg4_step in ("split", "overlap")
+        if split:
+            launch_mode = ("per step: cagym_step_begin (k_step_pre3: obstacle + agent half-planes and linear programs of the 9 RVO agents) %s "
+                           "cagym_ga3c_act (device-side selection + state vectors + fused forward, no host sync), then cagym_step_finish (k_step_post3: action maps + "
+                           "dynamics, collisions + wall test, rewards, LaserScan, observations, auto-reset)" % ("on a side stream BESIDE" if args.cfg4_step == "overlap" else "in front of"))
+            wp = 4 if ", 4," in env.kernel_name(rollout=False, auto_reset=True) else 5  # worlds per workgroup of this handle's specialisation
+            kernel_name = "k_step_post3<256, 10, %d, true, true> (+ k_step_pre3<256, 10, %d, true>)" % (wp, wp)
+        else:
+            launch_mode = "per step: cagym_ga3c_act (device-side selection + state vectors + fused forward, no host sync) + cagym_step_autoreset (laser scan inside)"
+            kernel_name = env.kernel_name(rollout=False, auto_reset=True)
 
         # --halves H > 1: worlds are independent, so the rank's worlds are dealt to H handles, each on its own HIP stream: group A's
         # GA3C forward (fp32 MFMA) runs beside group B's env kernel (VALU / LDS, two workgroups per CU) instead of after it
@@ -263,8 +276,15 @@ def main():
 
         def one_step():
             if len(groups) == 1:
-                ga3c.act(ext)
-                env.step(ext, auto_reset=True)
+                if args.cfg4_step == "overlap":
+                    env.step_overlapped(ga3c.act, ext, auto_reset=True)
+                elif split:
+                    env.step_begin()
+                    ga3c.act(ext)
+                    env.step_finish(ext, auto_reset=True)
+                else:
+                    ga3c.act(ext)
+                    env.step(ext, auto_reset=True)
                 return
             main = torch.cuda.current_stream(device)
             for e_h, g_h, x_h, st_h in groups:
@@ -312,9 +332,21 @@ def main():
             t_nn = loop(lambda: ga3c.act(ext))
             t_env = loop(lambda: env.step(ext, auto_reset=True))
             n0 = env.N  # = N, or one group's worlds with --halves
-            return {"ga3c_evals_per_s": n0 / t_nn, "ga3c_ms_per_step": 1e3 * t_nn, "ga3c_tflops_fp32": n0 * 0.67e6 / t_nn / 1e12,
-                    "env_kernel_ms_per_step": 1e3 * t_env, "kernels_timed_alone_on_worlds": n0,
-                    "env_kernel_hbm_frac": balg * n0 * M / t_env / (HBM_PEAK_GBS * 1e9)}
+            r = {"ga3c_evals_per_s": n0 / t_nn, "ga3c_ms_per_step": 1e3 * t_nn, "ga3c_tflops_fp32": n0 * 0.67e6 / t_nn / 1e12,
+                 "fused_env_kernel_ms_per_step": 1e3 * t_env, "kernels_timed_alone_on_worlds": n0,
+                 "fused_env_kernel_hbm_frac": balg * n0 * M / t_env / (HBM_PEAK_GBS * 1e9)}
+            if split:
+                def both():
+                    env.step_begin()
+                    env.step_finish(ext, auto_reset=True)
+                t_pre = loop(env.step_begin)
+                t_both = loop(both)
+                # the env part of a split step, its two launches back to back on one stream with nothing beside them
+                r.update({"pre_kernel_ms": 1e3 * t_pre, "post_kernel_ms": 1e3 * (t_both - t_pre), "env_kernel_ms_per_step": 1e3 * t_both,
+                          "env_kernel_hbm_frac": balg * n0 * M / t_both / (HBM_PEAK_GBS * 1e9)})
+            else:
+                r.update({"env_kernel_ms_per_step": 1e3 * t_env, "env_kernel_hbm_frac": r["fused_env_kernel_hbm_frac"]})
+            return r
         extra["cfg4"] = cfg4_extra
     else:  # cfg5: env part (3 IG agents driven externally + 2 static targets + 15 NonCooperative) + planner primitives
         IG = importlib.import_module("gym-exploration-2d_amd.ig").InfoGain
@@ -579,7 +611,8 @@ def main():
         if args.config == "cfg4":  # the timed step holds three launches: the roofline object prices the env kernel alone
             line["roofline"].update({"achieved": line["cfg4"]["env_kernel_hbm_frac"] * HBM_PEAK_GBS, "frac": line["cfg4"]["env_kernel_hbm_frac"],
                                      "launch_ms": line["cfg4"]["env_kernel_ms_per_step"], "launch_ms_min": None, "launch_ms_max": None,
-                                     "note": "env kernel alone (cagym_step_autoreset incl. laser scan), timed in its own loop"})
+                                     "note": ("env part alone: cagym_step_begin + cagym_step_finish back to back on one stream (both launches incl. laser scan), timed in its own loop"
+                                              if args.cfg4_step != "fused" else "env kernel alone (cagym_step_autoreset incl. laser scan), timed in its own loop")})
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(M, pol, config=args.config)
         print(json.dumps(line), flush=True)

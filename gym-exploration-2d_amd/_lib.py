@@ -50,7 +50,7 @@ class CagymScenarioPtrs(C.Structure):
 
 
 EXPORTS = ["cagym_version", "cagym_create", "cagym_destroy", "cagym_last_error", "cagym_set_scenarios",
-           "cagym_reset", "cagym_step", "cagym_step_autoreset", "cagym_rollout", "cagym_get_state", "cagym_laserscan",
+           "cagym_reset", "cagym_step", "cagym_step_autoreset", "cagym_step_begin", "cagym_step_finish", "cagym_rollout", "cagym_get_state", "cagym_laserscan",
            "cagym_generate_scenarios", "cagym_get_scenarios", "cagym_occupancy_grid", "cagym_kernel_name"]
 
 _lib = None
@@ -78,6 +78,8 @@ def load():
     L.cagym_step.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(CagymOutputs), C.c_void_p]
     L.cagym_step_autoreset.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(CagymOutputs), C.c_void_p]
     L.cagym_rollout.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(CagymOutputs), C.c_void_p]
+    L.cagym_step_begin.argtypes = [C.c_void_p, C.c_void_p]
+    L.cagym_step_finish.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(CagymOutputs), C.c_int, C.c_void_p]
     L.cagym_get_state.argtypes = [C.c_void_p, C.POINTER(CagymStatePtrs)]
     L.cagym_laserscan.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.cagym_pack_episode_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]

@@ -58,6 +58,7 @@ class BatchedCollisionAvoidanceEnv(object):
         self.game_over = torch.zeros((N,), dtype=torch.uint8, device=dev)
         self._out = self._outputs(self.obs_oas, self.obs_ego, self.obs_laser, self.reward, self.flags, self.game_over)
         self._state = None
+        self._side = None  # side stream of step_overlapped (created on first use)
 
     # ---- plumbing ------------------------------------------------------------------------------
     @staticmethod
@@ -172,6 +173,39 @@ class BatchedCollisionAvoidanceEnv(object):
         rc = fn(self.h, None if a is None else a.data_ptr(), C.byref(self._out), self._stream())
         _lib.check(self.L, self.h, rc, "cagym_step")
         return self._obs(), self.reward, self.game_over, {"flags": self.flags}
+
+    # ---- the split step: env.step() in two launches (include/cagym.h: cagym_step_begin / cagym_step_finish) ------------------
+    def step_begin(self, stream=None):
+        """First half of step(): the internal RVO policies' half-planes and linear programs on the current state (they do not
+        depend on the external actions: env.py:287-340 gathers every agent's action before any agent moves).  `stream`: a
+        torch.cuda.Stream to run it on BESIDE the producer of the external actions (default: the current stream); the caller
+        orders step_finish behind it (step_overlapped does)."""
+        raw = self._stream() if stream is None else C.c_void_p(stream.cuda_stream)
+        _lib.check(self.L, self.h, self.L.cagym_step_begin(self.h, raw), "cagym_step_begin")
+
+    def step_finish(self, actions=None, auto_reset=False):
+        """Second half of step(): everything else, with every agent's action in hand.  Same results as step(), bit for bit."""
+        a = None
+        if actions is not None:
+            a = torch.as_tensor(actions, device=self.device).to(torch.float32).reshape(self.N, self.M, 2).contiguous()
+        rc = self.L.cagym_step_finish(self.h, None if a is None else a.data_ptr(), C.byref(self._out), int(bool(auto_reset)), self._stream())
+        _lib.check(self.L, self.h, rc, "cagym_step_finish")
+        return self._obs(), self.reward, self.game_over, {"flags": self.flags}
+
+    def step_overlapped(self, policy, actions, auto_reset=False):
+        """step() with a device policy in the loop: `policy(actions)` fills the external actions on the current stream (e.g.
+        GA3CCADRLPolicy.act) WHILE the RVO half of the step runs on a side stream; the rest of the step follows both.
+        Worth it when the policy leaves the GPU idle (a host-side or remote policy).  NOT for cagym_ga3c_act on the same GPU:
+        measured on MI355X (profiles/r4/cfg4_overlap_trace_*.txt) the two kernels do run side by side, but sharing the CUs halves
+        each one's occupancy and both take twice as long - 0.251 ms per cfg4 step against 0.194 ms for the fused launch."""
+        main = torch.cuda.current_stream(self.device)
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        self._side.wait_stream(main)          # the previous step's state
+        self.step_begin(stream=self._side)
+        policy(actions)
+        main.wait_stream(self._side)
+        return self.step_finish(actions, auto_reset=auto_reset)
 
     def alloc_rollout(self, n_steps, obs=True):
         T, N, M, K, dev = int(n_steps), self.N, self.M, self.K, self.device

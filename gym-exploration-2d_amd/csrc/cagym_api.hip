@@ -10,6 +10,7 @@
 #include "../../include/cagym.h"
 #include "cagym_kernels.h"
 #include "cagym_kernels3.h"  // LDS layout helpers; the kernels themselves are instantiated in the cagym_k3_tu.hip units
+#include "cagym_split3.h"
 #include "cagym_launch3.h"
 #ifdef CAGYM_MONOLITHIC  // diagnostic builds: every generation-3 specialisation in this one translation unit
 #include "cagym_k3_all.inc"
@@ -42,6 +43,9 @@ struct Env {
     int obst_rvo = 0;    // RVO agents in worlds with rectangles: the kernels build obstacle half-planes (OBST instantiations)
     int generation = 3;  // CAGYM_KERNEL=v1 selects the one-lane-per-agent kernels (bitwise A/B only)
     int wpw10 = 5;       // worlds per workgroup of the M = 10 kernels (4 while all workgroups are co-resident)
+    size_t pre_lds_min = 0;  // CAGYM_PRE_LDS (bytes, read at creation): the PRE half asks for at least this much LDS per workgroup - a cap on how
+                             // many of its workgroups share a CU with the caller's policy kernel (tools/cfg4_overlap.py)
+    bool begun = false;  // cagym_step_begin was enqueued and no cagym_step_finish has consumed its velocities yet
 };
 
 int fail(Env* e, int code, const std::string& msg) {
@@ -151,6 +155,11 @@ inline size_t lds3_bytes(const Env* e, bool obst, bool lines) {
 inline bool has_map(const Env* e) { return e->cfg.max_obstacles > 0; }
 inline size_t scan_bytes(const Env* e) { return (size_t)e->cfg.n_worlds * e->cfg.max_agents * 16 * sizeof(float); }
 inline size_t lds3_bytes(const Env* e) { return lds3_bytes(e, has_map(e), e->obst_rvo != 0); }
+// the one-step launch of a handle with rectangles runs on the time-shared layout (carve_lds3_ovl)
+inline size_t lds3_step_bytes(const Env* e) {
+    if (!has_map(e)) return lds3_bytes(e);
+    return cagym_lds3_ovl_bytes(e->cfg.max_agents, cagym_as(e->cfg.max_agents, wpw_spec(e)), spec2(e).nt, e->D.ko);
+}
 // LP group width of the handle's specialisation (run_steps3)
 inline int lp_group_width(const Env* e) {
     const int mt = spec2(e).mt;
@@ -184,7 +193,7 @@ inline const K3Entry* k3_entry(const Env* e) {
 inline void launch3(const Env* e, bool rollout, bool auto_reset, const float* ext, int n_steps, const CagymOut& o, hipStream_t st) {
     K3Launch L;
     L.D = e->D; L.ext = ext; L.out = o; L.n_steps = n_steps; L.any_rvo = e->any_rvo; L.rollout = rollout; L.auto_reset = auto_reset;
-    L.grid = (unsigned)n_wg2(e); L.lds = lds3_bytes(e); L.stream = st;
+    L.grid = (unsigned)n_wg2(e); L.lds = rollout ? lds3_bytes(e) : lds3_step_bytes(e); L.stream = st;
 #ifdef CAGYM_DIAG_LDS_PAD  // occupancy experiments only (tools/README.md): unused LDS bytes on top, to force fewer workgroups per CU
     if (const char* pad = getenv("CAGYM_LDS_PAD")) L.lds += (size_t)atoi(pad);
 #endif
@@ -254,6 +263,7 @@ int cagym_create(const cagym_config* cfg, void** env_out) {
     A(dalloc(e, &D.aux0, NM)); A(dalloc(e, &D.aux1, NM)); A(dalloc(e, &D.coop, NM));
     A(dalloc(e, &D.action, NM * 2)); A(dalloc(e, &D.status, NM)); A(dalloc(e, &D.step_num, NM));
     A(dalloc(e, &D.n_observed, NM));
+    A(dalloc(e, &D.lp_vel, NM));
     A(dalloc(e, &D.n_agents, N)); A(dalloc(e, &D.episode, N)); A(dalloc(e, &D.ep_len, N));
     A(dalloc(e, &D.ep_return, N)); A(dalloc(e, &D.stat_return, N)); A(dalloc(e, &D.stat_episodes, N));
     A(dalloc(e, &D.stat_steps, N)); A(dalloc(e, &D.stat_outcomes, N * 3));
@@ -306,6 +316,7 @@ int cagym_create(const cagym_config* cfg, void** env_out) {
                 const int n4 = per_cu(4), n5 = per_cu(5);
                 e->wpw10 = n4 > n5 ? 4 : 5;
             }
+            if (const char* pl = getenv("CAGYM_PRE_LDS")) e->pre_lds_min = (size_t)atol(pl);
             const char* w = getenv("CAGYM_WPW10");  // diagnostics
             if (w && (w[0] == '4' || w[0] == '5')) e->wpw10 = w[0] - '0';
         }
@@ -527,6 +538,7 @@ int cagym_reset(void* env, const uint8_t* world_mask, int advance_episode, const
     DEVGUARD(e);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     CagymOut o = to_out(out);
+    e->begun = false;
     hipLaunchKernelGGL(k_reset, dim3(n_waves(e)), dim3(64), cagym_lds_bytes(e->cfg.max_agents), st, e->D, world_mask,
                        advance_episode, o);
     HIPCHK(e, hipGetLastError());
@@ -539,6 +551,7 @@ int cagym_step(void* env, const float* ext_actions, const cagym_outputs* out, vo
     if (!e) return fail(nullptr, CAGYM_E_INVALID, "null env");
     if (!e->scenarios_set) return fail(e, CAGYM_E_STATE, "cagym_step before cagym_set_scenarios");
     DEVGUARD(e);
+    e->begun = false;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     CagymOut o = to_out(out);
     if (!e->cfg.laserscan) o.laserscan = nullptr;
@@ -559,6 +572,7 @@ int cagym_step_autoreset(void* env, const float* ext_actions, const cagym_output
     if (!e) return fail(nullptr, CAGYM_E_INVALID, "null env");
     if (!e->scenarios_set) return fail(e, CAGYM_E_STATE, "cagym_step_autoreset before cagym_set_scenarios");
     DEVGUARD(e);
+    e->begun = false;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     CagymOut o = to_out(out);
     if (!e->cfg.laserscan) o.laserscan = nullptr;
@@ -571,11 +585,56 @@ int cagym_step_autoreset(void* env, const float* ext_actions, const cagym_output
     return CAGYM_OK;  // the scan of the (possibly restarted) worlds is part of the launch
 }
 
+// ---- the split step (csrc/cagym_split3.h) -----------------------------------------------------------------------------------------
+int cagym_step_begin(void* env, void* stream) {
+    Env* e = reinterpret_cast<Env*>(env);
+    if (!e) return fail(nullptr, CAGYM_E_INVALID, "null env");
+    if (!e->scenarios_set) return fail(e, CAGYM_E_STATE, "cagym_step_begin before cagym_set_scenarios");
+    if (e->generation != 3) return fail(e, CAGYM_E_UNSUPPORTED, "the split step needs the generation-3 kernels");
+    DEVGUARD(e);
+    e->begun = true;
+    if (!e->any_rvo) return CAGYM_OK;  // no internal RVO policy: nothing to solve ahead of the external actions
+    K3Launch L;
+    L.D = e->D; L.ext = nullptr; L.out = CagymOut{}; L.n_steps = 1; L.any_rvo = 1; L.rollout = false; L.auto_reset = false;
+    L.half = K3_HALF_PRE;
+    L.grid = (unsigned)n_wg2(e);
+    L.lds = cagym_lds3_pre_bytes(e->cfg.max_agents, cagym_as(e->cfg.max_agents, wpw_spec(e)), spec2(e).nt, has_map(e) ? e->D.ko : 0);
+    if (L.lds < e->pre_lds_min && e->pre_lds_min <= 64 * 1024) L.lds = e->pre_lds_min;
+    L.stream = reinterpret_cast<hipStream_t>(stream);
+    k3_entry(e)->launch[has_map(e) ? 1 : 0](L);
+    HIPCHK(e, hipGetLastError());
+    return CAGYM_OK;
+}
+
+int cagym_step_finish(void* env, const float* ext_actions, const cagym_outputs* out, int auto_reset, void* stream) {
+    Env* e = reinterpret_cast<Env*>(env);
+    if (!e) return fail(nullptr, CAGYM_E_INVALID, "null env");
+    if (!e->scenarios_set) return fail(e, CAGYM_E_STATE, "cagym_step_finish before cagym_set_scenarios");
+    if (e->generation != 3) return fail(e, CAGYM_E_UNSUPPORTED, "the split step needs the generation-3 kernels");
+    if (!e->begun) return fail(e, CAGYM_E_STATE, "cagym_step_finish without a cagym_step_begin on the current state");
+    DEVGUARD(e);
+    e->begun = false;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    CagymOut o = to_out(out);
+    if (!e->cfg.laserscan) o.laserscan = nullptr;
+    K3Launch L;
+    L.D = e->D; L.ext = ext_actions; L.out = o; L.n_steps = 1; L.any_rvo = 0; L.rollout = false; L.auto_reset = auto_reset != 0;
+    L.half = K3_HALF_POST;
+    L.grid = (unsigned)n_wg2(e);
+    L.lds = cagym_lds3_post_bytes(e->cfg.max_agents, cagym_as(e->cfg.max_agents, wpw_spec(e)), has_map(e) ? e->D.ko / 2 : 0, has_map(e));
+    L.stream = st;
+    k3_entry(e)->launch[has_map(e) ? 1 : 0](L);
+    HIPCHK(e, hipGetLastError());
+    if (!has_map(e) && o.laserscan) HIPCHK(e, hipMemsetAsync(o.laserscan, 0, scan_bytes(e), st));  // empty map: 0.0 everywhere
+    return CAGYM_OK;
+}
+
 int cagym_rollout(void* env, int n_steps, int auto_reset, const cagym_outputs* out, void* stream) {
     Env* e = reinterpret_cast<Env*>(env);
     if (!e) return fail(nullptr, CAGYM_E_INVALID, "null env");
     if (!e->scenarios_set) return fail(e, CAGYM_E_STATE, "cagym_rollout before cagym_set_scenarios");
     DEVGUARD(e);
+    e->begun = false;
     if (n_steps < 1) return fail(e, CAGYM_E_INVALID, "n_steps must be >= 1");
     if (e->cfg.laserscan && out && out->laserscan && e->generation != 3)
         return fail(e, CAGYM_E_UNSUPPORTED, "cagym_rollout produces laserscan with the generation-3 kernels only");

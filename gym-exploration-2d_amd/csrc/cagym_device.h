@@ -51,6 +51,8 @@ struct CagymDev {
     float* ep_return;
     float* stat_return;
     int32_t *stat_episodes, *stat_steps, *stat_outcomes;
+    float2* lp_vel;       // [N*M] the split step's hand-over (cagym_step_begin -> cagym_step_finish): every RVO ego's new velocity
+                          // (Agent::computeNewVelocity's result, or its clipped preferred velocity when no half-plane was violated)
     int32_t* dev_status;  // host-mapped word: CAGYM_DEVERR_* written by a kernel whose bounded wait expired (cagym_spin.h); 0 otherwise
 };
 

@@ -230,6 +230,74 @@ __device__ __forceinline__ Lds3 carve_lds3(unsigned char* smem, int M, int AS, i
     return W;
 }
 
+// ---- the split step (cagym_step_begin / cagym_step_finish, cagym_split3.h) ------------------------------------------------------
+// POST half (S1 with the actions of every policy in hand -> pair phase -> S2 + LaserScan -> observations): run_steps3 itself in
+// its one-step form with no RVO work left to do, on a carve WITHOUT the half-plane rows, the LP scratch and the neighbour keys
+// (cfg4: 53.4 -> 17 KB); krect = rectangles staged per world (the LaserScan's slab test), 0 = none
+__host__ __device__ inline size_t cagym_lds3_post_bytes(int M, int AS, int krect, bool obst) {
+    const size_t MP = cagym_mp(M);
+    return a16(cagym_lds3_head(AS)) + AS * MP * 8 + (size_t)AS * 8 + a16(AS * MP) + (size_t)(AS / M) * krect * 64 +
+           (obst ? a16((size_t)AS * 48 + 16) + (size_t)AS * 16 : 0);
+}
+__device__ __forceinline__ Lds3 carve_lds3_post(unsigned char* smem, int M, int AS, int krect) {
+    Lds3 W = carve_lds3(smem, M, AS, 0, 0, 0, false, 1);  // the head's pointers (every size argument below the head is unused here)
+    const size_t MP = cagym_mp(M);
+    W.dsq = nullptr; W.sorted = nullptr; W.lp3 = nullptr; W.cov = nullptr;
+    W.keys = reinterpret_cast<double*>(smem + a16(cagym_lds3_head(AS)));
+    W.gmin = reinterpret_cast<unsigned long long*>(W.keys + AS * MP);
+    W.hit = reinterpret_cast<uint8_t*>(W.gmin + AS);
+    W.rect = reinterpret_cast<float4*>(reinterpret_cast<unsigned char*>(W.hit) + a16(AS * MP));
+    W.blist = reinterpret_cast<uint16_t*>(reinterpret_cast<unsigned char*>(W.rect) + (size_t)(AS / M) * krect * 64);
+    W.wall = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(W.blist) + a16((size_t)AS * 48 + 16));
+    return W;
+}
+
+// ---- the ONE-step launch among rectangles (k_step3, OBST): time-shared LDS ("OVL") ----------------------------------------------------
+// A one-step launch runs its phases exactly once, in order: [rectangles, obstacle half-planes, neighbour keys, agent half-planes,
+// linear programs] and then [S1, pair phase + wall test, S2 + LaserScan, observations].  What the first group keeps in LDS - the
+// half-plane rows `sorted` and the scratch of the candidate lists / neighbour keys / projected lines - is dead once the linear
+// programs are solved; what the second group needs - OAS keys, collision bits, gap minima, beam list, wall-test records - is not
+// alive before.  They share bytes: cfg4 53.4 -> 39.8 KB = a FOURTH workgroup per CU, and its 2 048 workgroups are exactly two rounds
+// instead of 2.67 (profiles/r4/cfg4_timeline.txt).  The scratch itself is one region for three consumers alive one after the other
+// (cagym_split3.h's PRE half uses the same scheme): obstacle_lines_phase3's candidate lists (13 B per (ego, candidate)), then the
+// neighbour keys `dsq`, then the LP groups' projected lines (2 GW float4 per group, orca_lp_group_n<.., PC>).
+__host__ __device__ inline size_t cagym_ovl3_scratch(int M, int AS, int NT, int ko) {
+    const size_t lists = a16((size_t)13 * ko * AS), keys = a16((size_t)AS * cagym_mp(M) * 8), proj = (size_t)2 * NT * 16;
+    return lists > keys ? (lists > proj ? lists : proj) : (keys > proj ? keys : proj);
+}
+// the coverage bits of obstacle_lines_phase3 live in the agent rows of `sorted` (written by the half-plane lanes afterwards) when they fit
+__host__ __device__ inline bool cagym_ovl3_cov_aliased(int M, int AS, int ko) { return a16((size_t)ko * AS * 4) <= (size_t)(M - 1) * AS * 16; }
+__host__ __device__ inline size_t cagym_ovl3_late(int M, int AS) {  // keys, gmin, hit, beam list, wall records
+    const size_t MP = cagym_mp(M);
+    return (size_t)AS * MP * 8 + (size_t)AS * 8 + a16(AS * MP) + a16((size_t)AS * 48 + 16) + (size_t)AS * 16;
+}
+__host__ __device__ inline size_t cagym_lds3_ovl_bytes(int M, int AS, int NT, int ko) {
+    const size_t early = (size_t)(ko + M - 1) * AS * 16 + cagym_ovl3_scratch(M, AS, NT, ko), late = cagym_ovl3_late(M, AS);
+    return a16(cagym_lds3_head(AS)) + (size_t)(AS / M) * (ko / 2) * 64 + (early > late ? early : late) +
+           (cagym_ovl3_cov_aliased(M, AS, ko) ? 0 : a16((size_t)ko * AS * 4));
+}
+__device__ __forceinline__ Lds3 carve_lds3_ovl(unsigned char* smem, int M, int AS, int NT, int ko) {
+    Lds3 W = carve_lds3(smem, M, AS, 0, 0, 0, false, 1);  // the head's pointers
+    const size_t MP = cagym_mp(M);
+    unsigned char* u = smem + a16(cagym_lds3_head(AS));
+    W.rect = reinterpret_cast<float4*>(u);
+    u += (size_t)(AS / M) * (ko / 2) * 64;
+    // early: rows, then the scratch
+    W.sorted = reinterpret_cast<float4*>(u);
+    W.lp3 = reinterpret_cast<float4*>(u + (size_t)(ko + M - 1) * AS * 16);
+    W.dsq = reinterpret_cast<uint2*>(W.lp3);
+    // late: the same bytes from the region's start
+    W.keys = reinterpret_cast<double*>(u);
+    W.gmin = reinterpret_cast<unsigned long long*>(W.keys + AS * MP);
+    W.hit = reinterpret_cast<uint8_t*>(W.gmin + AS);
+    W.blist = reinterpret_cast<uint16_t*>(reinterpret_cast<unsigned char*>(W.hit) + a16(AS * MP));
+    W.wall = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(W.blist) + a16((size_t)AS * 48 + 16));
+    const size_t early = (size_t)(ko + M - 1) * AS * 16 + cagym_ovl3_scratch(M, AS, NT, ko), late = cagym_ovl3_late(M, AS);
+    W.cov = cagym_ovl3_cov_aliased(M, AS, ko) ? reinterpret_cast<uint32_t*>(W.sorted + (size_t)ko * AS)
+                                              : reinterpret_cast<uint32_t*>(u + (early > late ? early : late));
+    return W;
+}
+
 // the prepared rectangles (and their count) of every world of the workgroup: HBM -> LDS, all lanes; W.wsc must be visible
 __device__ __forceinline__ void stage_rects3(const CagymDev& D, const Lds3& W, int wpw, int worlds_valid) {
     const int per = D.Kobs * 4;
@@ -538,7 +606,8 @@ __device__ __forceinline__ double gap_of_key(unsigned long long k) {
 // ---- phase A body: pair distances of the moved state (env.py:630-655), OAS sort keys, fp32 squared distances ------------
 // GAP: fold the pair's gap into the lower agent's running minimum (phase A only: S2 consumes and resets it; the prologue's and the
 // reset path's calls rebuild keys / distances for the NEXT step's half-planes and rows and must leave it alone)
-template <int MT, bool GAP>
+// DSQ: also the ORCA ranking keys (not in the POST half of a split step: the next step's half-planes are another launch's)
+template <int MT, bool GAP, bool DSQ = true>
 __device__ __forceinline__ void pair_distances3(const CagymDev& D, const Lds3& W, int p, int M, int MP) {
     const UPair q = upair_of<MT>(p, M);
     const int n = W.wn[q.wl];
@@ -567,6 +636,26 @@ __device__ __forceinline__ void pair_distances3(const CagymDev& D, const Lds3& W
     if (GAP && gp < INFINITY) atomicMin(&W.gmin[lo], gap_key(gp));  // (no lane waits for the result: ds_min_u64 without return)
     W.keys[lo * MP + shi] = klo;
     W.keys[hi * MP + slo] = khi;
+    if (DSQ) {
+        W.dsq[lo * MP + shi] = make_uint2((uint32_t)shi, __float_as_uint(dq));
+        W.dsq[hi * MP + slo] = make_uint2((uint32_t)slo, __float_as_uint(dq));
+    }
+}
+
+// the ORCA ranking keys of one unordered pair alone (pair_distances3 without the collision / observation half): what a one-step
+// launch needs ahead of its own half-planes (its rows of step t - 1 do not exist)
+template <int MT>
+__device__ __forceinline__ void pair_dsq3(const Lds3& W, int p, int M, int MP) {
+    const UPair q = upair_of<MT>(p, M);
+    const int n = W.wn[q.wl];
+    const int lo = q.wl * M + (q.i < q.j ? q.i : q.j), hi = q.wl * M + (q.i < q.j ? q.j : q.i);
+    const int slo = lo - q.wl * M, shi = hi - q.wl * M;
+    float dq = INFINITY;
+    if (shi < n) {
+        // Agent::computeNewVelocity's distSq of the pair, fp32: (float)p_other - (float)p_ego, squared (sign-symmetric)
+        const float rpx = (float)W.tpx[hi] - (float)W.tpx[lo], rpy = (float)W.tpy[hi] - (float)W.tpy[lo];
+        dq = rpx * rpx + rpy * rpy;
+    }
     W.dsq[lo * MP + shi] = make_uint2((uint32_t)shi, __float_as_uint(dq));
     W.dsq[hi * MP + slo] = make_uint2((uint32_t)slo, __float_as_uint(dq));
 }
@@ -932,7 +1021,9 @@ __device__ __forceinline__ CagymOut out_slice3(const CagymOut& out, int t, size_
 // them (D.ko > 0) - obstacle half-planes with LP groups of 4 half-planes per lane.  The free-space instantiation carries
 // none of that code (it cost the headline kernel 7 VGPRs and a spill).
 // ONE: the one-step launch (k_step3: n_steps == 1 at compile time)
-template <int NT, int MT, int WPWT, bool AUTO_RESET, bool OBST, bool ONE = false>
+// POST: the second half of a split step (k_step_post3, needs ONE and any_rvo == false): the RVO egos' new velocities were solved by
+// k_step_pre3 (D.lp_vel); no half-plane rows / LP scratch / neighbour keys in LDS (carve_lds3_post)
+template <int NT, int MT, int WPWT, bool AUTO_RESET, bool OBST, bool ONE = false, bool POST = false>
 __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const float* ext, const CagymOut& out, int n_steps,
                                   bool any_rvo) {
     constexpr int NWAVES = NT / CAGYM_WAVE;
@@ -943,8 +1034,10 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
     const int AS = cagym_as(M, WPWT);
     const int ko = OBST ? D.ko : 0;  // 2 * Kobs: an agent outside a rectangle sees at most 2 of its edges from their right side
     constexpr int LPL = cagym_lpl3(MT, OBST);
-    const Lds3 W = carve_lds3(smem, M, AS, NT, ko, LPL, OBST, MT);
-    const bool dsq_shared = OBST ? cagym_obst_alias(M, AS, NT, ko, LPL) : cagym_dsq_aliased(false, MT);  // the neighbour keys live in the LP scratch
+    constexpr bool OVL = ONE && OBST && !POST;  // the one-step launch among rectangles: early and late arrays share LDS bytes (carve_lds3_ovl)
+    const Lds3 W = POST ? carve_lds3_post(smem, M, AS, ko / 2) : OVL ? carve_lds3_ovl(smem, M, AS, NT, ko) : carve_lds3(smem, M, AS, NT, ko, LPL, OBST, MT);
+    // the neighbour keys live in the LP scratch (a one-step launch builds no half-planes for a next step: no keys after its prologue)
+    const bool dsq_shared = !ONE && (OBST ? cagym_obst_alias(M, AS, NT, ko, LPL) : cagym_dsq_aliased(false, MT));
     LaneCtx C = make_ctx2(D, M, WPWT ? WPWT : CAGYM_WAVE / M);
     const uint32_t inv_m = (uint32_t)(0x100000000ull / (uint32_t)M) + 1u;
     const int nagents = C.wpw * M;               // agent slots of this workgroup (<= 64: wave 0)
@@ -969,19 +1062,23 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
             W.tmoved[tid] = 0;
             W.trvo[tid] = live_rvo(A.st, C.valid && C.active);
             W.nobl[tid] = 0;
-            W.gmin[tid] = CAGYM_GAP_INF;
+            if (!OVL) W.gmin[tid] = CAGYM_GAP_INF;  // (OVL: the late arrays are initialised behind the linear programs, whose rows they overlay)
             if (C.wl < C.wpw && C.slot == 0) {
                 W.wn[C.wl] = C.valid ? C.n : 0;
                 W.wsc[C.wl] = C.valid ? (int)(((long long)C.world + (long long)C.episode * D.N) % D.S) : 0;
             }
             // constant entries of the distance / key rows: own slot and the padding
-            W.dsq[tid * MP + C.slot] = make_uint2((uint32_t)C.slot, 0x7f800000u);
-            W.hit[tid * MP + C.slot] = 0;
-            W.keys[tid * MP + C.slot] = -INFINITY;
+            if (!POST && !OVL) W.dsq[tid * MP + C.slot] = make_uint2((uint32_t)C.slot, 0x7f800000u);
+            if (!OVL) {
+                W.hit[tid * MP + C.slot] = 0;
+                W.keys[tid * MP + C.slot] = -INFINITY;
+            }
             for (int l = M; l < MP; l++) {
-                W.dsq[tid * MP + l] = make_uint2((uint32_t)l, 0x7f800000u);
-                W.hit[tid * MP + l] = 0;
-                W.keys[tid * MP + l] = -INFINITY;
+                if (!POST && !OVL) W.dsq[tid * MP + l] = make_uint2((uint32_t)l, 0x7f800000u);
+                if (!OVL) {
+                    W.hit[tid * MP + l] = 0;
+                    W.keys[tid * MP + l] = -INFINITY;
+                }
             }
         }
         if (tid < 16) W.flag[tid] = 0;
@@ -1000,7 +1097,16 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
         }
         WGTRACE1(22);
         if (any_rvo) {
-            for (int p = tid; p < nup; p += NT) pair_distances3<MT, false>(D, W, p, M, MP);
+            if (OVL && agent_lane) {
+                // the neighbour keys take the bytes of the candidate lists: those are dead once every lane has passed the last barrier
+                // inside obstacle_lines_phase3 (its last sub-step, on the last wave, reads the coverage bits and the rows only)
+                W.dsq[tid * MP + C.slot] = make_uint2((uint32_t)C.slot, 0x7f800000u);
+                for (int l = M; l < MP; l++) W.dsq[tid * MP + l] = make_uint2((uint32_t)l, 0x7f800000u);
+            }
+            for (int p = tid; p < nup; p += NT) {
+                if (ONE) pair_dsq3<MT>(W, p, M, MP);  // (no rows of a step t - 1 to serve: the OAS keys / collision bits come with phase A)
+                else pair_distances3<MT, false>(D, W, p, M, MP);
+            }
             __syncthreads();
             WGTRACE1(23);
             for (int p = tid; p < nup; p += NT) half_planes3<MT>(D, W, p, M, MP, AS, ko);
@@ -1067,10 +1173,11 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
                     if (OBST) {
                         // two half-planes per lane serve 2 GW lines; only a wave that holds an ego with more runs the 4-per-lane code
                         const int nol = W.nobl[a];
+                        float4* P = W.lp3 + (OVL ? 2 : LPL) * (tid & ~(GW - 1));  // (OVL: projected agent lines only, PC)
                         if (__ballot(nol + nn > 2 * GW) != 0ull)
-                            orca_lp_group_n<GW, LPL>(W.sorted, W.lp3 + LPL * (tid & ~(GW - 1)), a, j, nol, nn, ko, rad, pv.x, pv.y, vx, vy, AS, &W.flag[3]);
+                            orca_lp_group_n<GW, LPL, OVL>(W.sorted, P, a, j, nol, nn, ko, rad, pv.x, pv.y, vx, vy, AS, &W.flag[3]);
                         else
-                            orca_lp_group_n<GW, 2>(W.sorted, W.lp3 + LPL * (tid & ~(GW - 1)), a, j, nol, nn, ko, rad, pv.x, pv.y, vx, vy, AS, &W.flag[3]);
+                            orca_lp_group_n<GW, 2, OVL>(W.sorted, P, a, j, nol, nn, ko, rad, pv.x, pv.y, vx, vy, AS, &W.flag[3]);
                     } else {
                         orca_lp_group<GW, TWO, (MT > 0 ? MT - 1 : 0)>(W.sorted, W.lp3 + LPL * (tid & ~(GW - 1)), a, j, nn, rad, pv.x, pv.y, vx, vy, AS, &W.flag[3],
                                                                       LPCOUNT_DBG(), LPWT_ROWS(t, base));
@@ -1123,7 +1230,10 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
                             break;
                         case CAGYM_POL_CARRL: d0 = 1.0; d1 = carrl_heading(ext ? (int)ext[2 * aidx] : 0); break;
                         case CAGYM_POL_RVO: {
-                            const float2 v = W.lpc[tid];  // LP result, or the clipped preferred velocity of an ego that needed none
+                            // LP result, or the clipped preferred velocity of an ego that needed none (split step: from k_step_pre3)
+                            float2 v;
+                            if (POST) v = D.lp_vel[aidx];
+                            else v = W.lpc[tid];
                             orca_post(A, v.x, v.y, D.dt, D.inv_dt, d0, d1, &hint);
                             break;
                         }
@@ -1133,7 +1243,7 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
                 }
                 asm volatile("" :: "v"(a0), "v"(a1));
                 WAVETRACE(t, 15);
-                if (TWO && !OBST) {
+                if (TWO && !OBST && !POST) {
                     // M = 20 and the run-time-M kernels are held to 128 VGPRs (the whole launch co-resident) and the compiler kept the
                     // hint's three doubles alive through take_action in SCRATCH memory: two dependent round trips of ~600 cycles on the
                     // chain.  The LP scratch is dead here (every LP wave is done, phase A's keys come after the next barrier): the hint
@@ -1166,6 +1276,15 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
         } else if (agent_lane) {
             W.tmoved[tid] = 0;
         }
+        if (OVL && agent_lane) {  // the late arrays start their life here, in the bytes of the half-plane rows the linear programs are done with
+            W.gmin[tid] = CAGYM_GAP_INF;
+            W.hit[tid * MP + C.slot] = 0;
+            W.keys[tid * MP + C.slot] = -INFINITY;
+            for (int l = M; l < MP; l++) {
+                W.hit[tid * MP + l] = 0;
+                W.keys[tid * MP + l] = -INFINITY;
+            }
+        }
         if (tid == NT - 1) { W.flag[1] = 0; W.flag[2] = 0; W.flag[4] = W.flag[3]; W.flag[3] = 0; W.flag[7] = 0; W.flag[8] = 0; W.flag[9] = 0; W.flag[10] = 0; }
         __syncthreads();
         WGTRACE1(26);
@@ -1185,7 +1304,7 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
             for (int l = M; l < MP; l++) W.dsq[tid * MP + l] = make_uint2((uint32_t)l, 0x7f800000u);
         }
         PMARK("A_pairs_begin");
-        for (int p = tid; p < nup; p += NT) pair_distances3<MT, true>(D, W, p, M, MP);
+        for (int p = tid; p < nup; p += NT) pair_distances3<MT, true, !ONE>(D, W, p, M, MP);
         PMARK("A_pairs_end");
         WAVETRACE(t, 8);
         const bool obst_lines = OBST && ko > 0 && any_rvo && t + 1 < n_steps;
@@ -1325,7 +1444,7 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
                     if (any_rvo && more) ego_lp_inputs3<OBST>(D, W, a, M, AS, ko, inv_m);
                 }
             }
-            for (int p = tid; p < nup; p += NT) pair_distances3<MT, false>(D, W, p, M, MP);
+            for (int p = tid; p < nup; p += NT) pair_distances3<MT, false, !ONE>(D, W, p, M, MP);
             if (OBST && ko > 0 && any_rvo && more) {
                 __syncthreads();
                 obstacle_lines_phase3(D, W, M, AS, ko, nagents, inv_m);
@@ -1378,8 +1497,9 @@ __global__ void __launch_bounds__(NT, OBST ? 2 : cagym_min_waves3(NT, MT)) k_rol
 }
 
 // one step with external actions; the output buffers are NOT sliced (out_slice3 with t = 0 is the identity)
+// (OBST: held to 128 VGPRs - with the time-shared LDS of the one-step launch (carve_lds3_ovl) four workgroups share a CU)
 template <int NT, int MT, int WPWT, bool AUTO_RESET, bool OBST>
-__global__ void __launch_bounds__(NT, OBST ? 2 : cagym_min_waves3(NT, MT)) k_step3(CagymDev D, const float* ext, CagymOut out, int any_rvo) {
+__global__ void __launch_bounds__(NT, OBST ? (NT > 256 ? 2 : 4) : cagym_min_waves3(NT, MT)) k_step3(CagymDev D, const float* ext, CagymOut out, int any_rvo) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     WGTRACE(0);
     WGTRACE_VALUE(39, 0);

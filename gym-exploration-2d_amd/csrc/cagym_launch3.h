@@ -12,8 +12,11 @@
 // lanes per workgroup, compile-time M (0 = run-time M), worlds per workgroup (0 = 64 / M worlds, LDS stride 64)
 #define CAGYM_K3_SPECS(X) X(256, 10, 4) X(256, 10, 5) X(256, 4, 0) X(256, 20, 2) X(256, 0, 0) X(512, 0, 0)
 
+enum { K3_HALF_NONE = 0, K3_HALF_PRE = 1, K3_HALF_POST = 2 };  // the split step's two launches (cagym_split3.h)
+
 struct K3Launch {
     CagymDev D;
+    int half = K3_HALF_NONE;
     const float* ext;   // k_step3: external actions (may be null)
     CagymOut out;
     int n_steps;        // k_rollout3

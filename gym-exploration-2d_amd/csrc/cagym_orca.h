@@ -691,7 +691,9 @@ __device__ __forceinline__ bool orca_edge_covered_by(const float4* rects, int id
 // ---- linearProgram2/3 on a GW-lane group with LPL half-planes per lane and protected obstacle lines ----------------------
 // Line q of the solve (q < no: obstacle line q, row q of the ego's column; q >= no: agent line q - no, row ko + q - no)
 // lives on lane q % GW, slot q / GW.  linearProgram3 keeps the obstacle lines as they are and projects only the agent
-// lines (RVO2: projLines(lines.begin(), lines.begin() + numObstLines)).  n = no + nn <= GW * LPL.  P: LPL * GW entries.
+// lines (RVO2: projLines(lines.begin(), lines.begin() + numObstLines)).  n = no + nn <= GW * LPL.  P: LPL * GW entries, or -
+// PC ("projected lines compact", the split step's PRE half) - nn <= 2 GW entries: the projected set's obstacle lines are read
+// from their rows of L, only the projected agent lines are kept in P (at q - no): same values, half the scratch.
 template <int GW, int LPL>
 __device__ __forceinline__ uint64_t orca_group_mask(const bool (&v)[LPL], int gbase) {
     const uint64_t gbits = (1ull << GW) - 1ull;
@@ -733,7 +735,7 @@ __device__ __forceinline__ float2 orca_group_chord(const float2 (&c)[LPL], int q
         if (slot == k) { sx = c[k].x; sy = c[k].y; }
     return make_float2(__shfl(sx, own, 64), __shfl(sy, own, 64));
 }
-template <int GW, int LPL>
+template <int GW, int LPL, bool PC = false>
 __device__ inline void orca_lp_group_n(const float4* L, float4* P, int a, int j, int no, int nn, int ko, float radius, float ox,
                                        float oy, float& rx, float& ry, int stride, int* lp3_flag = nullptr) {
     const int gbase = (threadIdx.x & 63) & ~(GW - 1);
@@ -813,7 +815,9 @@ __device__ inline void orca_lp_group_n(const float4* L, float4* P, int a, int j,
                 have[c] = orca_project(li, l[c], p[c]);
                 if (have[c]) pch[c] = orca_chord(p[c], radius);
             }
-            if (have[c]) P[q] = p[c];
+            if (PC) {
+                if (have[c] && q >= no) P[q - no] = p[c];
+            } else if (have[c]) P[q] = p[c];
         }
         const int np = i > no ? i : no;  // projected lines occupy indices < max(i, no)
         const float px = -li.w, py = li.z;
@@ -831,7 +835,7 @@ __device__ inline void orca_lp_group_n(const float4* L, float4* P, int a, int j,
             if (!um) break;
             const int k = __ffsll((unsigned long long)um) - 1;
             kcur = k + 1;
-            const float4 pk = P[k];
+            const float4 pk = PC ? *(k < no ? L + (k * stride + a) : P + (k - no)) : P[k];  // (PC: both are LDS addresses)
             bool take[LPL];
 #pragma unroll
             for (int c = 0; c < LPL; c++) take[c] = have[c] && j + c * GW < k;

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CAGYM_VERSION 111 /* 0.1.1: cagym_config.rvo_max_neighbors, cagym_kernel_name */
+#define CAGYM_VERSION 112 /* 0.1.2: cagym_step_begin / cagym_step_finish, CAGYM_E_DEVICE */
 
 enum { CAGYM_OK = 0, CAGYM_E_INVALID = -1, CAGYM_E_NODEVICE = -2, CAGYM_E_HIP = -3, CAGYM_E_NOMEM = -4,
        CAGYM_E_STATE = -5, CAGYM_E_UNSUPPORTED = -6,
@@ -140,6 +140,21 @@ int cagym_step(void* env, const float* ext_actions, const cagym_outputs* out, vo
  * for this step -- OtherAgentsStates, scalar keys and, with cfg.laserscan, the laser scan (_get_obs runs every sensor,
  * env.py:740-753) -- is the first one of the new episode (reward / flags / game_over are the terminal ones). */
 int cagym_step_autoreset(void* env, const float* ext_actions, const cagym_outputs* out, void* stream);
+
+/* step(actions) in TWO launches, for callers whose external actions come from a device policy of their own (cfg4: cagym_ga3c_act).
+ * _take_action (env.py:287-340) gathers the actions of ALL agents before any agent moves, and an internal RVO policy
+ * (policies/RVOPolicy.py:53-117) reads the state BEFORE the step only - so the RVO half of the step does not have to wait for the
+ * external actions:
+ *   cagym_step_begin   the ORCA half-planes (agents and rectangles) and linear programs of every live RVO ego on the current state;
+ *                      8 bytes per agent are kept on the handle.  Enqueue it on a stream of its own, beside the policy that
+ *                      produces ext_actions; it reads the state, never writes it.  A no-op for handles without RVO agents.
+ *   cagym_step_finish  the rest of the step (action maps + dynamics with every action in hand, collisions, rewards, done /
+ *                      game_over, observations, and - auto_reset != 0 - cagym_step_autoreset's restart).  The caller orders it
+ *                      behind BOTH the begin launch and the producer of ext_actions (stream / event dependencies).
+ * begin + finish produce bit for bit what cagym_step / cagym_step_autoreset produce (tests/test_split_step.py).  finish without
+ * a begin since the last finish / step / reset / rollout returns CAGYM_E_STATE.  Generation-3 kernels only. */
+int cagym_step_begin(void* env, void* stream);
+int cagym_step_finish(void* env, const float* ext_actions, const cagym_outputs* out, int auto_reset, void* stream);
 
 /* n_steps consecutive step() calls in ONE launch for worlds whose agents are all driven internally
  * (Static / NonCooperative / RVO): the agent records stay on chip, every step writes its outputs (laserscan

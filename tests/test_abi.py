@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
     assert "cagym_step" in syms and "cagym_rollout" in syms
     for s in syms:
         assert hasattr(L, s), "libcagym_hip.so does not export %s" % s
-    assert L.cagym_version() == 111
+    assert L.cagym_version() == 112
 
 
 def test_no_cpu_fallback():
