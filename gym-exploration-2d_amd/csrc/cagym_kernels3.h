@@ -1380,6 +1380,10 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
                         int l0 = rs ? ep_len : 0;
                         LaneCtx Cr = C;
                         Cr.valid = rs;
+                        // (opaque: as a loop invariant the four 64-bit addresses of the world's statistics were computed in front of the step
+                        // loop, found no register in the kernels held to 128 VGPRs - M = 20: 32 of its 36 bytes of scratch - and came back
+                        // one dependent reload + load after the other inside this rare path)
+                        asm volatile("" : "+v"(Cr.world));
                         fold_episode_stats(D, Cr, S, r0, l0);
                         if (rs) {
                             ep_ret = 0.f;
@@ -1390,7 +1394,12 @@ __device__ inline void run_steps3(const CagymDev& D, unsigned char* smem, const 
                             C.active = C.slot < C.n;
                             init_agent(D, S, sidx, C.slot, C.active);
                             lds3_store_agent(W, S, tid);
-                            if (C.slot == 0) { W.wn[C.wl] = C.n; W.wsc[C.wl] = sidx; }
+                            if (C.slot == 0) {
+                                int wlq = C.wl;  // (opaque for the same reason: the hoisted LDS address was the last spilled value of the M = 20 kernel)
+                                asm volatile("" : "+v"(wlq));
+                                W.wn[wlq] = C.n;
+                                W.wsc[wlq] = sidx;
+                            }
                         }
                     }
                 }
