@@ -47,6 +47,13 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
 B_STATE, B_OAS9, B_OAS19, B_LASER = 133.0, 384.0, 784.0, 64.0
 
 
+def profile_replay(name):
+    """Counters of a secondary configuration, collected by the rocprofv3 --pmc passes of tools/final_profile_r4.sh and stored by
+    tools/store_profiles_r4.py (profiles/r4/<name>): replayed into the line, labelled as such; None when the file is not there."""
+    q = os.path.join(ROOT, "profiles", "r4", name)
+    return json.load(open(q)) if os.path.exists(q) else None
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -127,7 +134,15 @@ def cpu_baseline(M, policy_id, seconds=12.0, worlds=2048, threads=None, config="
         el = time.perf_counter() - t0
         if el >= seconds:
             break
-    return {"value": worlds * steps / el, "unit": "env-steps/s", "cores": threads, "kind": "port",
+    # The reference's own Python env.step() cannot run on the GPU box (its source never travels): its figure is the one measured in the
+    # development container on the same scenario rule, reported beside the port with its source
+    ref_py = {4: (1260.0, 11939.0), 10: (457.0, 3412.0)}.get(M)
+    reference_python = None if ref_py is None else {
+        "value_1_process": ref_py[0], "value_8_processes": ref_py[1], "unit": "env-steps/s", "agents": M,
+        "policy": "NonCooperative (the rvo2 library the reference's RVOPolicy drives is absent: RVO could not be timed)",
+        "host": "8 vCPU Intel Xeon @ 2.10 GHz (development container), Python 3.10, NumPy 2.2",
+        "source": "BASELINE.md section 2: unmodified reference modules imported from the reference checkout, free-space random-goal episodes, auto-reset, 8 s per point; NOT measured in this run"}
+    return {"value": worlds * steps / el, "unit": "env-steps/s", "cores": threads, "kind": "port", "reference_python": reference_python,
             "sample": "%d worlds x %d agents, %d steps, %.1f s, C oracle (oracle/cagym_oracle.c) with its world loop on "
                       "%d OpenMP threads (omp_get_max_threads), finished worlds restart inside the C loop, same policy/scenario rule%s"
                       % (worlds, M, steps, el, threads, note)}
@@ -182,13 +197,13 @@ def main():
     side = torch.cuda.Stream(device=device) if world_size > 1 else None
     gathered = None
 
-    stats_state = {"every": 1, "block": 0, "collective_ms": None}
+    stats_state = {"every": 1, "block": 0, "collective_ms": None, "probing": False}
 
     def gather_stats(env, force=False):
         """Episode-statistics all-gather (multi-GPU only): one pack kernel on the main stream, the collective on the side
         stream; issued in one of every stats_state["every"] timed blocks (cumulative counters: nothing is lost)."""
         nonlocal gathered
-        if world_size > 1 and (force or stats_state["block"] % stats_state["every"] == 0):
+        if world_size > 1 and (force or (not stats_state["probing"] and stats_state["block"] % stats_state["every"] == 0)):
             local = env.packed_episode_stats()
             side.wait_stream(torch.cuda.current_stream(device))
             local.record_stream(side)  # allocated on the main stream, read by the collective on the side stream
@@ -364,8 +379,9 @@ def main():
         ext[:, :3, 0] = 2.0
         balg = B_STATE + B_OAS19
         workload = ("%d worlds x %d agents%s, env part: 3 information-gain agents (external (v, omega), FirstOrderDynamics), 2 static "
-                    "targets, 15 NonCooperative, rectangles, OtherAgentsStates [19, 10] (BASELINE configs[4]); `value` is the env part, the whole "
-                    "step with the belief update and the Dec-MCTS planning step at the experiment's budget is `cfg5.whole_loop_env_steps_per_s`" % (N, M, " on this rank" if world_size > 1 else ""))
+                    "targets, 15 NonCooperative, rectangles, OtherAgentsStates [19, 10] (BASELINE configs[4]); `value` is the env part with the IG agents driven at a "
+                    "CONSTANT (v, omega) = (2 m/s, 0) - a timing workload: they run into walls, 91 %% of its episodes end in collisions -, the whole "
+                    "step with the belief update and the Dec-MCTS planning step at the experiment's budget (planned actions) is `cfg5.whole_loop_env_steps_per_s`" % (N, M, " on this rank" if world_size > 1 else ""))
         launch_mode = "cagym_step_autoreset per step"
         kernel_name = env.kernel_name(rollout=False, auto_reset=True)
 
@@ -444,7 +460,15 @@ def main():
                     "planner_workspace_GB": planner.workspace.numel() / 1e9,
                     "visibility_queries_per_s": Q / t_vis, "rollouts_per_s_horizon4": Qr * nsims / t_ro,
                     "rollout_visibility_queries_per_s": Qr * nsims * H / t_ro,
-                    "l2_hit_rate": None, "l2_hit_rate_source": "profiles/ (rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum pass), not measured in this run"}
+                    **cfg5_counters()}
+
+        def cfg5_counters():
+            c = profile_replay("cfg5_planner_pmc.json")
+            src = "replayed from profiles/r4/cfg5_planner_pmc.json (rocprofv3 --pmc SQ / TCC passes of k_dmcts_plan on this workload), not measured in this run"
+            return {"planner_valu_busy": c and c.get("valu_busy"), "l2_hit_rate": c and c.get("l2_hit_rate"), "counters_source": src if c else None,
+                    "bound": "the planner (99.9 % of the step) is LATENCY-bound, not HBM- or MFMA-bound: a world's planning step is one serial chain of "
+                             "R x Ncycles x Ntree = 450 grows, each a chain of dependent gathers through the L2-resident distance field (sphere traces of "
+                             "the roll-outs' visibility queries); 8 worlds per CU x 2 waves fill the CU's 16 wave slots at 128 VGPRs"}
         extra["cfg5"] = cfg5_extra
 
     def barrier():
@@ -493,7 +517,7 @@ def main():
             barrier()
             tc.append(time.perf_counter() - t0)
         stats_state["collective_ms"] = 1e3 * sorted(tc)[2]
-        stats_state["every"] = 1 << 30  # not during the probe blocks below
+        stats_state["probing"] = True  # no collective inside the probe blocks below
     blocks = [timed_block()]
     if world_size > 1:
         # one block in `every` carries the collective: at most 1 % of the timed time, priced on the median of five probe
@@ -505,6 +529,7 @@ def main():
         r = torch.tensor([ev], dtype=torch.int64, device=device)
         dist.all_reduce(r, op=dist.ReduceOp.MAX)
         stats_state["every"] = int(r.item())
+        stats_state["probing"] = False
 
     def more_blocks(n):
         """rank 0 decides how many more blocks to time (0 = stop); every rank runs the same count"""
@@ -517,7 +542,7 @@ def main():
         return n
 
     if args.repeats > 0:
-        more_blocks(max(0, args.repeats - 1))
+        more_blocks(max(0, args.repeats - len(blocks)))  # (a multi-rank run has timed its 5 probe blocks already)
     else:  # at least 5 blocks, and short blocks are repeated until the timed blocks cover 2 s whatever --steps is
         while len(blocks) < 50000:
             covered = sum(b[0] for b in blocks if b[1] is None)  # the wall clock is taken from the blocks without HIP events
@@ -548,9 +573,10 @@ def main():
         # headline shape only and is labelled as such; null for any other shape.
         traffic = None
         replay = None  # counters of the headline shape, collected by the rocprofv3 --pmc passes of tools/final_profile_r3.sh
-        rp = os.path.join(ROOT, "profiles", "r3", "headline_pmc.json")
-        if (N, M, policy, args.per_step_launch) == (4096, 10, "rvo", False) and os.path.exists(rp):
+        rp = next((q for q in (os.path.join(ROOT, "profiles", r, "headline_pmc.json") for r in ("r4", "r3")) if os.path.exists(q)), None)
+        if (N, M, policy, args.per_step_launch) == (4096, 10, "rvo", False) and rp:
             replay = json.load(open(rp))
+        rp_name = os.path.relpath(rp, ROOT) if rp else None
         traffic_per_agent_step = (replay["hbm_bytes_per_agent_step"] + replay.get("hbm_bytes_per_agent_per_launch", 0.0) / steps_per_launch) if replay else None
         short_launch = steps_per_launch <= 32  # the driver's command: one 20-step launch per block
         if replay:
@@ -590,12 +616,12 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": None if traffic is None else
-                         "replayed from profiles/r3/headline_pmc.json (rocprofv3 --pmc passes of this shape: FETCH_SIZE x2 + WRITE_SIZE per agent-step), not measured in this run",
+                         "replayed from %s (rocprofv3 --pmc passes on %s-step launches of this shape: FETCH_SIZE x2 + WRITE_SIZE per agent-step, plus the per-launch load / store of the agent records spread over this run's %d steps per launch), not measured in this run" % (rp_name, replay.get("steps_per_launch", "512"), int(steps_per_launch)),
                          # what actually bounds the kernel (the HBM fraction above is the metric BASELINE.json asks for): VALU issue
                          # (a 20-step launch ends with its slowest workgroup: its own counters, where the profile has them)
                          "valu_busy": None if not replay else replay.get("valu_busy_20_step_launches", replay["valu_busy"]) if short_launch else replay["valu_busy"],
                          "valu_insts_per_agent_step": None if not replay else replay.get("valu_insts_per_agent_step_20_step_launches", replay["valu_insts_per_agent_step"]) if short_launch else replay["valu_insts_per_agent_step"],
-                         "valu_source": None if not replay else "replayed from profiles/r3/headline_pmc.json (SQ_ACTIVE_INST_VALU, SQ_INSTS_VALU, GRBM_GUI_ACTIVE of the %s-step launches), not measured in this run" % ("20" if short_launch and "valu_busy_20_step_launches" in replay else replay.get("steps_per_launch", "512")),
+                         "valu_source": None if not replay else "replayed from %s (SQ_ACTIVE_INST_VALU, SQ_INSTS_VALU, GRBM_GUI_ACTIVE of the %s-step launches), not measured in this run" % (rp_name, "20" if short_launch and "valu_busy_20_step_launches" in replay else replay.get("steps_per_launch", "512")),
                          "kernel": kernel_name,
                          "clock": "wall-clock median block (the clock of `value` and `ms_per_step`: frac = alg_bytes_per_agent_step x agents x worlds / ms_per_step / peak)",
                          "launch_ms": launch_ms, "launch_ms_min": 1e3 * walls[0] / launches, "launch_ms_max": 1e3 * walls[-1] / launches,
@@ -609,6 +635,11 @@ def main():
         for name, fn in extra.items():
             line[name] = fn()
         if args.config == "cfg4":  # the timed step holds three launches: the roofline object prices the env kernel alone
+            c4 = profile_replay("cfg4_pmc.json")
+            if c4:
+                line["roofline"].update({"valu_busy": c4.get("valu_busy"), "valu_insts_per_agent_step": c4.get("valu_insts_per_agent_step"),
+                                         "waves_per_simd": c4.get("waves_per_simd"),
+                                         "valu_source": "replayed from profiles/r4/cfg4_pmc.json (rocprofv3 --pmc SQ pass of the env kernel on this workload), not measured in this run"})
             line["roofline"].update({"achieved": line["cfg4"]["env_kernel_hbm_frac"] * HBM_PEAK_GBS, "frac": line["cfg4"]["env_kernel_hbm_frac"],
                                      "launch_ms": line["cfg4"]["env_kernel_ms_per_step"], "launch_ms_min": None, "launch_ms_max": None,
                                      "note": ("env part alone: cagym_step_begin + cagym_step_finish back to back on one stream (both launches incl. laser scan), timed in its own loop"

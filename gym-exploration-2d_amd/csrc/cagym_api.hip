@@ -977,7 +977,7 @@ size_t cagym_dmcts_workspace_bytes(int n_worlds, const cagym_dmcts_params* p) {
     if (!p || n_worlds < 1 || p->n_robots < 1 || p->Ntree < 1 || p->Ncycles < 1) return 0;
     const size_t trees = (size_t)n_worlds * p->n_robots;
     return dm_align(trees * sizeof(DmPublished)) + dm_align(trees * 2 * sizeof(int32_t)) + dm_align(trees * (size_t)dm_node_cap(*p) * sizeof(DmNode)) +
-           trees * (size_t)dm_mask_cap(*p) * sizeof(DmMasks);
+           dm_align(trees * (size_t)dm_mask_cap(*p) * sizeof(DmMasks)) + trees * (size_t)dm_node_cap(*p) * sizeof(double);  // (last: the trees' compact value arrays)
 }
 
 int cagym_dmcts_plan(void* env, const cagym_dmcts_params* params, const double* poses, void* workspace,
@@ -1001,12 +1001,13 @@ int cagym_dmcts_plan(void* env, const cagym_dmcts_params* params, const double* 
     int32_t* nn = reinterpret_cast<int32_t*>(base + dm_align(trees * sizeof(DmPublished)));
     DmNode* nodes = reinterpret_cast<DmNode*>(base + dm_align(trees * sizeof(DmPublished)) + dm_align(trees * 2 * sizeof(int32_t)));
     DmMasks* masks = reinterpret_cast<DmMasks*>(reinterpret_cast<unsigned char*>(nodes) + dm_align(trees * (size_t)dm_node_cap(p) * sizeof(DmNode)));
+    double* mu = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(masks) + dm_align(trees * (size_t)dm_mask_cap(p) * sizeof(DmMasks)));
     if (p.reset_comms) HIPCHK(e, hipMemsetAsync(pub, 0, trees * sizeof(DmPublished), st));
     DmParams P;
     P.R = p.n_robots; P.Ntree = p.Ntree; P.Nsims = p.Nsims; P.horizon = p.horizon; P.Ncycles = p.Ncycles; P.comm_n = p.comm_n;
     P.node_cap = dm_node_cap(p); P.mask_cap = dm_mask_cap(p); P.xdt = p.xdt; P.call_base = p.call_base;
     P.c_p = p.c_p; P.gamma = p.gamma; P.radius = p.radius; P.dt = p.dt; P.fov = p.fov_rad; P.range = p.range; P.seed = p.seed;
-    hipLaunchKernelGGL(k_dmcts_plan, dim3((unsigned)N), dim3(DM_THREADS), 0, st, e->G, P, poses, nodes, masks, nn, pub, actions, paths, stats);
+    hipLaunchKernelGGL(k_dmcts_plan, dim3((unsigned)N), dim3(DM_THREADS), 0, st, e->G, P, poses, nodes, masks, mu, nn, pub, actions, paths, stats);
     HIPCHK(e, hipGetLastError());
     return CAGYM_OK;
 }

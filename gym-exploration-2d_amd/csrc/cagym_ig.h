@@ -108,10 +108,26 @@ __device__ __forceinline__ double ig_clamp(double v) {
     return a > -IG_HALF ? a : -IG_HALF;
 }
 
+// The two tangents of the cone test's fast path (below): they depend on the field of view alone.  A caller that asks for many
+// visibility sets with one field of view (the planner: one per roll-out step) evaluates them once - two fp64 library tangents
+// were ~300 of a query's instructions.
+struct IgCone {
+    double t_in, t_out;
+    bool fast;
+};
+__device__ __forceinline__ IgCone ig_cone(double fov) {
+    const double hf = fov / 2;
+    IgCone c;
+    c.fast = hf > 1e-6 && hf < 1.5;
+    c.t_in = c.fast ? tan(hf - 1e-9) : 0.0;
+    c.t_out = c.fast ? tan(hf + 1e-9) : 0.0;
+    return c;
+}
+
 // targetMap.getVisibleCells (targetMap.py:43-84), computed by all `nthreads` threads of a block into the
 // LDS mask `vis[60]` (zeroed here).  Ends with a barrier.
 __device__ inline void ig_visible_block(const uint32_t* d2, double px, double py, double phi, double fov, double range,
-                                        unsigned long long* vis, int tid, int nthreads) {
+                                        unsigned long long* vis, int tid, int nthreads, const IgCone* cone = nullptr) {
     for (int j = tid; j < IG_BEL; j += nthreads) vis[j] = 0ull;
     __syncthreads();
     double s, c;
@@ -135,9 +151,9 @@ __device__ inline void ig_visible_block(const uint32_t* d2, double px, double py
     // window cell, and two cells in three fail it.  A cell that is inside or outside by a margin far above the rounding of
     // either side is decided by products alone (|r1| against r0 tan(fov/2 -+ 1e-9), rn^2 against range^2 (1 -+ 1e-12)); only
     // a cell within those margins evaluates the reference's own expressions.  Same set, bit for bit.
-    const double hf = fov / 2;
-    const bool fast = hf > 1e-6 && hf < 1.5;
-    const double t_in = fast ? tan(hf - 1e-9) : 0.0, t_out = fast ? tan(hf + 1e-9) : 0.0;
+    const IgCone cn = cone ? *cone : ig_cone(fov);
+    const bool fast = cn.fast;
+    const double t_in = cn.t_in, t_out = cn.t_out;
     const double r2_in = range * range * (1.0 - 1e-12), r2_out = range * range * (1.0 + 1e-12);
     for (int q = tid; q < total; q += nthreads) {
         int i = xs + q / h, j = ys + q % h;
