@@ -262,24 +262,28 @@ __global__ void __launch_bounds__(320) k_ig_edt_cols(IgDev G, uint32_t* any_flag
     if (any) atomicOr(&any_flag[s], 1u);
 }
 
-// EDT, pass 2: per row, lower envelope by brute force (300 candidates per cell), in place.
+// EDT, pass 2: per row, lower envelope by brute force (300 candidates per cell), in place.  Every quantity fits 32 bits - a finite
+// column distance is <= 299, so a squared distance is <= 2 * 299^2 - and the candidates' squares are taken once per row (round 4: the
+// loop ran on 64-bit integers with a multiplication per candidate, 66.6 ms per scenario upload against 6.7 ms for pass 1).
 __global__ void __launch_bounds__(320) k_ig_edt_rows(IgDev G, const uint32_t* any_flag) {
-    __shared__ uint32_t grow[CAGYM_MAPD];
+    __shared__ uint32_t g2[CAGYM_MAPD];  // squared column distance of the row's cells; 0x7fff0000 = no occupied cell in that column
     const int s = blockIdx.x / CAGYM_MAPD, y = blockIdx.x % CAGYM_MAPD, x = threadIdx.x;
     uint32_t* row = G.d2 + ((size_t)s * CAGYM_MAPD + y) * CAGYM_MAPD;
-    if (x < CAGYM_MAPD) grow[x] = row[x];
+    if (x < CAGYM_MAPD) {
+        const uint32_t gy = row[x];
+        g2[x] = gy >= (1u << 19) ? 0x7fff0000u : gy * gy;
+    }
     __syncthreads();
     if (x >= CAGYM_MAPD) return;
-    long long best = 2LL * CAGYM_MAPD * CAGYM_MAPD;
+    uint32_t best = 2u * CAGYM_MAPD * CAGYM_MAPD;
     if (any_flag[s]) {
         for (int xx = 0; xx < CAGYM_MAPD; xx++) {
-            long long gy = grow[xx];
-            if (gy >= (1 << 19)) continue;
-            long long d = (long long)(x - xx) * (x - xx) + gy * gy;
-            if (d < best) best = d;
+            const int dx = x - xx;
+            const uint32_t d = (uint32_t)(dx * dx) + g2[xx];  // (< 2^31 + 2^17: no wrap; a column without an occupied cell never wins)
+            best = d < best ? d : best;
         }
     }
-    row[x] = (uint32_t)best;
+    row[x] = best;
 }
 
 __global__ void __launch_bounds__(256) k_ig_fill_belief(IgDev G, const uint8_t* mask) {
