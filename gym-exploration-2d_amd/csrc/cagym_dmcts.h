@@ -616,6 +616,7 @@ __global__ void __launch_bounds__(DM_THREADS, DM_WAVES_PER_SIMD) k_dmcts_plan(Ig
                 }
                 __syncthreads();
                 DMSTAMP(7);
+                DMSTAMP_FLUSH();
             }
             // ---- send_comms: publish this robot's distribution (ig_mcts.py:107) ------------------------------------------
             const int n = dist_n[r];

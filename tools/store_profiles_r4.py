@@ -127,7 +127,7 @@ if have("cfg4_pmc/p1.txt"):
     p = O + "cfg4_pmc/p1.txt"
     a, g, n = avg(p, "SQ_ACTIVE_INST_VALU"), avg(p, "GRBM_GUI_ACTIVE"), avg(p, "SQ_INSTS_VALU")
     wc, bc = avg(p, "SQ_WAVE_CYCLES"), avg(p, "SQ_BUSY_CU_CYCLES")
-    json.dump({"valu_busy": 4 * a / (1024 * g / 8), "valu_insts_per_agent_step": n / (8192 * 10), "waves_per_simd": (wc / bc / 4) if (wc and bc) else None,
+    json.dump({"valu_busy": 4 * a / (1024 * g / 8), "valu_insts_per_agent_step": n / (8192 * 10), "waves_per_simd": (4 * wc / (1024 * g / 8)) if wc else None,  # SQ_WAVE_CYCLES counts quad-cycles per resident wave
                "kernel_avg_us": dur(p) / 1e3, "source": "tools/cfg4_pmc.sh (rocprofv3 --pmc SQ pass of bench.py --config cfg4), env kernel k_step3<256, 10, 4, true, true>"},
               open(P + "cfg4_pmc.json", "w"), indent=1)
 if have("cfg5_prof/pmc_summary.txt"):
