@@ -311,16 +311,31 @@ __device__ inline bool dm_next_pose_wave(const uint32_t* d2, double& x, double& 
 // item of a roll-out: 57 iterations with an integer division and a 64-bit shift each, whatever the mask held.)
 __device__ inline double dm_reward_wave(const double* belief, const unsigned long long* mask, int lane) {
     double a0 = 0.0, a1 = 0.0;
+    // six rows' cached values are requested together (a lane's cell of a row outside the mask requests nothing): the world's MI cache
+    // misses the L1 more often than not (eight worlds' distance-field gathers share it), and one request per row was one dependent round
+    // trip to the L2 per non-empty row
+    constexpr int RB = 6;
 #pragma unroll 1
-    for (int j = 0; j < IG_BEL; j++) {
-        const unsigned long long row = mask[j];  // the same word on every lane
-        if (__builtin_amdgcn_readfirstlane((int)((row | (row >> 32)) != 0ull)) == 0) continue;
-        const int i = (lane + 4 * j) & 63;
-        if (i < IG_BEL && ((row >> i) & 1ull)) {
+    for (int j0 = 0; j0 < IG_BEL; j0 += RB) {
+        double v[RB];
+        bool hi[RB], on[RB];
+#pragma unroll
+        for (int u = 0; u < RB; u++) {
+            const int j = j0 + u;
+            const unsigned long long row = mask[j];  // the same word on every lane
+            const int i = (lane + 4 * j) & 63;
             const int q = j * IG_BEL + i;
-            const double v = belief[q];
-            if (((q - lane) >> 6) & 1) a1 += v;
-            else a0 += v;
+            on[u] = i < IG_BEL && ((row >> i) & 1ull);
+            hi[u] = ((q - lane) >> 6) & 1;
+            v[u] = 0.0;
+            if (on[u]) v[u] = belief[q];
+        }
+#pragma unroll
+        for (int u = 0; u < RB; u++) {  // rows in ascending order: each virtual thread's cells in ascending q
+            if (on[u]) {
+                if (hi[u]) a1 += v[u];
+                else a0 += v[u];
+            }
         }
     }
     double r = a0 + a1;
