@@ -41,7 +41,11 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wno-unused-value",
          # MachineLICM hoists ~70 fp64 polynomial literals (sincos/atan2) out of the rollout's step loop and
          # keeps them in VGPRs: 168 VGPRs + spills instead of 106 (measured)
-         "-mllvm", "-disable-machine-licm"]
+         "-mllvm", "-disable-machine-licm",
+         # no automatic packing of fp32 pairs: on gfx950 a v_pk_mul/add_f32 issues in 4.5 - 4.9 cycles against 2.6 - 3.0 for the scalar
+         # op (tools/micro/pk_f32_rate.hip), and the SLP vectorizer's 168 packed operations + their register shuffling cost the
+         # headline kernel 1.9 % (profiles/r4/ab_compiler_flags.txt: 512-step launch 3.873 -> 3.804 ms)
+         "-fno-slp-vectorize"]
 
 
 def units():
