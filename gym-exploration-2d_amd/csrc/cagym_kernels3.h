@@ -731,37 +731,39 @@ __device__ __forceinline__ void oas_row3(const Lds3& W, float* oas_out, int p, i
     const int n = W.wn[q.wl];
     float* my = oas_out + ((size_t)blockIdx.x * wpw * M + q.a) * K * 10;
     const double kj = W.keys[q.a * MP + q.j];
-    float v[10];
-    int row;
     if (!(kj > -INFINITY)) {  // unused row: zero (rows n-1 .. K-1 of an active agent, every row of an empty slot)
-        row = q.sl < n ? q.j - 1 : (q.j < q.sl ? q.j : q.j - 1);
+        // (its own stores: merged with the live rows' values through a common array, the zeros cost ~20 register moves per chunk)
+        const int row = q.sl < n ? q.j - 1 : (q.j < q.sl ? q.j : q.j - 1);
+        float2* r2 = reinterpret_cast<float2*>(my + row * 10);
+        const float2 z = make_float2(0.f, 0.f);
 #pragma unroll
-        for (int c = 0; c < 10; c++) v[c] = 0.f;
-    } else {
-        int before = 0;  // descending key, ties by descending index (stable sort, reversed: :28-34)
-        const double2* krow = reinterpret_cast<const double2*>(W.keys + q.a * MP);
-        for (int l2 = 0; l2 < M; l2 += 2) {  // keys beyond the world's slots (and the pad of an odd M) are -inf
-            const double2 kk = krow[l2 >> 1];
-            before += (kk.x > kj) || (kk.x == kj && l2 + 0 > q.j);
-            before += (kk.y > kj) || (kk.y == kj && l2 + 1 > q.j);
-        }
-        row = before;
-        PMARK("oas_ranked");
-        const int b = q.a - q.sl + q.j;
-        const double dx = W.tpx[b] - W.tpx[q.a], dy = W.tpy[b] - W.tpy[q.a];
-        const double prx = W.tprx[q.a], pry = W.tpry[q.a], orx = -pry, ory = prx;
-        const double ovx = W.tvx[b], ovy = W.tvy[b], orad = W.tr[b];
-        v[0] = (float)dx;
-        v[1] = (float)dy;
-        v[2] = (float)dot2(dx, dy, prx, pry);
-        v[3] = (float)dot2(dx, dy, orx, ory);
-        v[4] = (float)dot2(ovx, ovy, prx, pry);
-        v[5] = (float)dot2(ovx, ovy, orx, ory);
-        v[6] = (float)orad;
-        v[7] = (float)(W.tr[q.a] + orad);
-        v[8] = (float)kj;
-        v[9] = ST_POLICY(W.tst[b]) == CAGYM_POL_STATIC ? 1.f : 2.f;
+        for (int c = 0; c < 5; c++) r2[c] = z;
+        return;
     }
+    int before = 0;  // descending key, ties by descending index (stable sort, reversed: :28-34)
+    const double2* krow = reinterpret_cast<const double2*>(W.keys + q.a * MP);
+    for (int l2 = 0; l2 < M; l2 += 2) {  // keys beyond the world's slots (and the pad of an odd M) are -inf
+        const double2 kk = krow[l2 >> 1];
+        before += (kk.x > kj) || (kk.x == kj && l2 + 0 > q.j);
+        before += (kk.y > kj) || (kk.y == kj && l2 + 1 > q.j);
+    }
+    const int row = before;
+    PMARK("oas_ranked");
+    const int b = q.a - q.sl + q.j;
+    const double dx = W.tpx[b] - W.tpx[q.a], dy = W.tpy[b] - W.tpy[q.a];
+    const double prx = W.tprx[q.a], pry = W.tpry[q.a], orx = -pry, ory = prx;
+    const double ovx = W.tvx[b], ovy = W.tvy[b], orad = W.tr[b];
+    float v[10];
+    v[0] = (float)dx;
+    v[1] = (float)dy;
+    v[2] = (float)dot2(dx, dy, prx, pry);
+    v[3] = (float)dot2(dx, dy, orx, ory);
+    v[4] = (float)dot2(ovx, ovy, prx, pry);
+    v[5] = (float)dot2(ovx, ovy, orx, ory);
+    v[6] = (float)orad;
+    v[7] = (float)(W.tr[q.a] + orad);
+    v[8] = (float)kj;
+    v[9] = ST_POLICY(W.tst[b]) == CAGYM_POL_STATIC ? 1.f : 2.f;
     PMARK("oas_store");
     float2* r2 = reinterpret_cast<float2*>(my + row * 10);  // rows are 40 B: 8-byte aligned
 #pragma unroll
