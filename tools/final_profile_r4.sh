@@ -49,6 +49,8 @@ CAGYM_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 20 --warmup 5 --no-cpu
 echo rehearsal done
 python tools/launch_cost.py > $O/launch_cost.txt 2>&1
 echo launch cost done
+tools/valu_breakdown.sh $O/valu 2>&1 | grep -v amdgpu.ids > $O/valu_breakdown.txt
+echo breakdown done
 fi
 if [ $PART = c ]; then
 python bench.py --config cfg4 --steps 200 --warmup 50 > $O/bench_cfg4.json 2> $O/bench_cfg4.err

@@ -116,6 +116,7 @@ if have("sweep.txt"):
 if have("rehearsal_2ranks_gloo_driver_cmd.json"):
     open(P + "rehearsal_2ranks_one_gpu_gloo_driver_cmd.json", "w").write(json.dumps(last_json(O + "rehearsal_2ranks_gloo_driver_cmd.json")) + "\n")
 cp("launch_cost.txt")
+cp("valu_breakdown.txt")
 
 # ---- part c: cfg4 / cfg5 ----------------------------------------------------------------------------------------------------------------
 for a in ("bench_cfg4.json", "bench_cfg4_split.json", "bench_cfg4_overlap.json", "bench_cfg5.json", "cfg4_timeline.txt", "cfg4_pmc.txt", "dmcts_phases.txt"):
