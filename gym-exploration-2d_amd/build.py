@@ -21,7 +21,7 @@ OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(CSRC, "libcagym_hip.so")
 K3_HEADERS = ["cagym_device.h", "cagym_trace.h", "cagym_spin.h", "cagym_orca.h", "cagym_kernels.h", "cagym_kernels3.h", "cagym_split3.h", "cagym_launch3.h",
               "../../include/cagym.h"]
-HEADERS = K3_HEADERS + ["cagym_ig.h", "cagym_ga3c.h", "cagym_gen.h", "cagym_dmcts.h"]
+HEADERS = K3_HEADERS + ["cagym_ig.h", "cagym_ga3c.h", "cagym_ga3c16.h", "cagym_gen.h", "cagym_dmcts.h"]
 
 
 def _k3_specs():

@@ -17,6 +17,7 @@
 #endif
 #include "cagym_ig.h"
 #include "cagym_ga3c.h"
+#include "cagym_ga3c16.h"
 #include "cagym_gen.h"
 #include "cagym_dmcts.h"
 
@@ -37,6 +38,8 @@ struct Env {
     uint32_t* ig_any = nullptr;
     int32_t* gen_failed = nullptr;  // device word: agents whose rejection loop hit max_tries (cagym_generate_scenarios)
     int32_t* ga3c_ctr = nullptr;    // device words of cagym_ga3c_act's list (k_ga3c_select): ticket, list start, list length
+    unsigned char* ga3c_packed = nullptr;   // the weight blob as split f16 operand fragments (k_ga3c_pack16, cagym_ga3c16.h)
+    const float* ga3c_packed_src = nullptr; // the blob it was packed from (cagym_ga3c_load_weights)
     int32_t* status_host = nullptr; // host-mapped word the kernels' bounded waits report into (CagymDev::dev_status, cagym_spin.h)
     bool ig_ready = false;
     int any_rvo = 1;
@@ -268,6 +271,7 @@ int cagym_create(const cagym_config* cfg, void** env_out) {
     A(dalloc(e, &D.ep_return, N)); A(dalloc(e, &D.stat_return, N)); A(dalloc(e, &D.stat_episodes, N));
     A(dalloc(e, &D.stat_steps, N)); A(dalloc(e, &D.stat_outcomes, N * 3));
     A(dalloc(e, &e->ga3c_ctr, 4));  // at creation: cagym_ga3c_act may run inside a stream capture (no allocation there)
+    A(dalloc(e, &e->ga3c_packed, GA16_PACKED_BYTES));
 #undef A
     {   // the kernels' status word: pinned host memory mapped into the device's address space (written only when a bounded wait expires)
         void* hp = nullptr;
@@ -728,6 +732,39 @@ int cagym_pack_episode_stats(void* env, int32_t* records, void* stream) {
     return CAGYM_OK;
 }
 
+// which forward kernel (read per call: the A/B tests flip it inside one process): default = split-f16 matrix cores
+// (cagym_ga3c16.h); CAGYM_GA3C=mfma32: round 2's exact-fp32 matrix-core kernel; =valu: round 1's vector kernel
+enum { GA_KERNEL_H16 = 0, GA_KERNEL_MFMA32 = 1, GA_KERNEL_VALU = 2, GA_KERNEL_BAD = -1 };
+static int ga3c_kernel_choice() {
+    const char* which = getenv("CAGYM_GA3C");
+    if (!which || !which[0] || !strcmp(which, "h16")) return GA_KERNEL_H16;
+    if (!strcmp(which, "mfma32")) return GA_KERNEL_MFMA32;
+    if (!strcmp(which, "valu")) return GA_KERNEL_VALU;
+    return GA_KERNEL_BAD;
+}
+
+// the handle's packed copy of `weights`: made on `st` the first time a blob (by address) is used; a caller that rewrites the
+// blob in place says so with cagym_ga3c_load_weights
+static int ga3c_pack(Env* e, const float* weights, hipStream_t st, bool force) {
+    if (!force && e->ga3c_packed_src == weights) return CAGYM_OK;
+    hipLaunchKernelGGL(k_ga3c_pack16, dim3((GA16_PACK_THREADS + 255) / 256), dim3(256), 0, st, weights, e->ga3c_packed);
+    const hipError_t s = hipGetLastError();
+    if (s != hipSuccess) {
+        e->ga3c_packed_src = nullptr;
+        return fail(e, CAGYM_E_HIP, std::string("k_ga3c_pack16: ") + hipGetErrorString(s));
+    }
+    e->ga3c_packed_src = weights;
+    return CAGYM_OK;
+}
+
+int cagym_ga3c_load_weights(void* env, const float* weights, void* stream) {
+    Env* e = reinterpret_cast<Env*>(env);
+    if (!e) return fail(nullptr, CAGYM_E_INVALID, "null env");
+    if (!weights) return fail(e, CAGYM_E_INVALID, "null weights");
+    DEVGUARD(e);
+    return ga3c_pack(e, weights, reinterpret_cast<hipStream_t>(stream), true);
+}
+
 static void launch_ga3c_state(Env* e, int max_observed, const int32_t* agent_idx, long long rows, uint32_t* ctr, float* state,
                               hipStream_t st) {
     if (e->cfg.max_agents <= 16)
@@ -760,6 +797,10 @@ int cagym_ga3c_act(void* env, const float* weights, int max_observed, void* work
         return fail(e, CAGYM_E_INVALID, "bad arguments (max_observed in 1..10)");
     DEVGUARD(e);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int which = ga3c_kernel_choice();
+    if (which == GA_KERNEL_BAD) return fail(e, CAGYM_E_INVALID, "CAGYM_GA3C: unknown forward kernel (h16, mfma32 or valu)");
+    if (which == GA_KERNEL_H16)
+        if (int rc = ga3c_pack(e, weights, st, false)) return rc;
     const size_t total = (size_t)e->cfg.n_worlds * e->cfg.max_agents;
     int32_t* idx = reinterpret_cast<int32_t*>(reinterpret_cast<unsigned char*>(work) + 256);
     float* state = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(work) + 256 + a16(total * sizeof(int32_t)));
@@ -778,9 +819,13 @@ int cagym_ga3c_act(void* env, const float* weights, int max_observed, void* work
     // the list length stays on the device: both kernels are launched for the worst case and leave beyond it
     launch_ga3c_state(e, max_observed, idx, (long long)total, ctr, state, st);
     if (int rc = launched("k_ga3c_state")) return rc;
-    hipLaunchKernelGGL(k_ga3c_forward_mfma, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, st, weights, state, idx, 0, e->ga3c_ctr + 2, e->D.pref,
-                       ext_actions, (int32_t*)nullptr, (float*)nullptr, ctr);
-    if (int rc = launched("k_ga3c_forward_mfma")) return rc;
+    if (which == GA_KERNEL_H16)
+        hipLaunchKernelGGL(k_ga3c_forward_h16, dim3((unsigned)((total + 31) / 32)), dim3(512), 0, st, e->ga3c_packed, state, idx, 0, e->ga3c_ctr + 2,
+                           e->D.pref, ext_actions, (int32_t*)nullptr, (float*)nullptr, ctr);
+    else  // the vector kernel has no device-side count: the fp32 matrix-core kernel stands in for it here
+        hipLaunchKernelGGL(k_ga3c_forward_mfma, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, st, weights, state, idx, 0, e->ga3c_ctr + 2, e->D.pref,
+                           ext_actions, (int32_t*)nullptr, (float*)nullptr, ctr);
+    if (int rc = launched("k_ga3c_forward")) return rc;
     return CAGYM_OK;
 }
 
@@ -818,9 +863,13 @@ int cagym_ga3c_forward(void* env, const float* weights, const float* state, cons
     DEVGUARD(e);
     // 32 agents per workgroup reuse every weight 32 times; small batches take 16 so that each CU still gets >= 2 workgroups
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const char* which = getenv("CAGYM_GA3C");  // read per call: the A/B test flips it inside one process
-    const bool use_valu = which && !strcmp(which, "valu");
-    if (!use_valu)  // default: the matrix-core kernel (CAGYM_GA3C=valu selects round 1's vector kernel, for A/B)
+    const int which = ga3c_kernel_choice();
+    if (which == GA_KERNEL_BAD) return fail(e, CAGYM_E_INVALID, "CAGYM_GA3C: unknown forward kernel (h16, mfma32 or valu)");
+    if (which == GA_KERNEL_H16) {
+        if (int rc = ga3c_pack(e, weights, st, false)) return rc;
+        hipLaunchKernelGGL(k_ga3c_forward_h16, dim3((unsigned)((B + 31) / 32)), dim3(512), 0, st, e->ga3c_packed, state, agent_idx, B,
+                           (const int32_t*)nullptr, e->D.pref, ext_actions, action_index, probs, (uint32_t*)nullptr);
+    } else if (which == GA_KERNEL_MFMA32)
         hipLaunchKernelGGL(k_ga3c_forward_mfma, dim3((unsigned)((B + 31) / 32)), dim3(256), 0, st, weights, state, agent_idx, B,
                            (const int32_t*)nullptr, e->D.pref, ext_actions, action_index, probs, (uint32_t*)nullptr);
     else if (B <= 16 * 1024)

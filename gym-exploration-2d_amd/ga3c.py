@@ -1,5 +1,6 @@
 """GA3C-CADRL policy on device: state-vector kernel (cagym_ga3c_state) + fused forward kernel
-(cagym_ga3c_forward: normalisation, LSTM-64, 3 x FC-256, logits, argmax, action table in ONE launch).
+(cagym_ga3c_forward: normalisation, LSTM-64, 3 x FC-256, logits, argmax, action table in ONE launch; since round 4 on the
+16-bit matrix cores with split fp32 operands, csrc/cagym_ga3c16.h - CAGYM_GA3C=mfma32 / valu select the exact-fp32 kernels).
 
 Replaces policies/GA3CCADRLPolicy.py:34-43 and GA3C_CADRL/network.py:65-98 (TensorFlow 1.15 session.run per
 agent) by one batched forward over every GA3C agent of every world.  Weights come from the converted checkpoint
@@ -40,6 +41,8 @@ class GA3CCADRLPolicy(object):
         self.L.cagym_ga3c_act_workspace_bytes.restype = C.c_size_t
         self.L.cagym_ga3c_act.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         self.L.cagym_ga3c_act.restype = C.c_int
+        self.L.cagym_ga3c_load_weights.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        self.L.cagym_ga3c_load_weights.restype = C.c_int
         self._work = None
         path = checkpoint if os.path.exists(checkpoint) else os.path.join(HERE, "weights", "ga3c_cadrl_%s.npz" % checkpoint)
         W = np.load(path)
@@ -56,6 +59,12 @@ class GA3CCADRLPolicy(object):
         assert self.blob.numel() == 170507
         self._idx = None
         self._idx_episode = None
+
+    def load_weights(self):
+        """Tell the handle that `self.blob` was rewritten in place (it caches the blob as matrix-core operand fragments by address)."""
+        with torch.cuda.device(self.b.device):
+            rc = self.L.cagym_ga3c_load_weights(self.b.h, self.blob.data_ptr(), self.b._stream())
+        _lib.check(self.L, self.b.h, rc, "cagym_ga3c_load_weights")
 
     def states(self):
         with torch.cuda.device(self.b.device):

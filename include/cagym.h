@@ -193,6 +193,12 @@ int cagym_ga3c_state(void* env, int max_observed, float* state, void* stream);
  * ext_actions[agent] = (pref_speed * a0, a1) (DEVICE [N,M,2] f32); action_index [B] i32 and probs [B,11] f32
  * (softmax_p) are optional. */
 #define CAGYM_GA3C_NWEIGHTS 170507
+/* The forward kernels multiply on gfx950's 16-bit matrix cores with every fp32 operand split into two f16 halves (three matrix
+ * instructions per product, fp32 accumulation: fp32-class accuracy, csrc/cagym_ga3c16.h).  The handle keeps the blob re-ordered
+ * into operand fragments; that copy is made on `stream` the first time cagym_ga3c_forward / cagym_ga3c_act see a blob ADDRESS.
+ * A caller that rewrites the same blob in place (training) calls cagym_ga3c_load_weights afterwards; one blob per handle is
+ * cached.  CAGYM_GA3C=mfma32 / valu (environment, read per call) select the exact-fp32 kernels of rounds 2 / 1 for A/B. */
+int cagym_ga3c_load_weights(void* env, const float* weights, void* stream);
 int cagym_ga3c_forward(void* env, const float* weights, const float* state, const int32_t* agent_idx, int B,
                        float* ext_actions, int32_t* action_index, float* probs, void* stream);
 

@@ -112,11 +112,23 @@ def test_hip_state_kernel_and_forward_and_behaviour():
     assert goal.mean() > 0.8 and coll.mean() < 0.1  # the trained policy does avoid collisions
 
 
+def _forward_with(policy, which, **kw):
+    import os
+    if which:
+        os.environ["CAGYM_GA3C"] = which
+    try:
+        return policy.forward(want_probs=True, **kw)
+    finally:
+        os.environ.pop("CAGYM_GA3C", None)
+
+
 @pytest.mark.gpu
 def test_matrix_core_and_vector_forward_kernels_agree():
-    """The fp32 MFMA kernel (default) against round 1's vector kernel (CAGYM_GA3C=valu) on live states, ragged batch sizes
-    (a partial 32-agent tile, agents with 0..9 observed others): same arg-max wherever the margin is clear, probabilities to 1e-5."""
-    import os
+    """The three forward kernels on live states, ragged batch sizes (a partial 32-agent tile, agents with 0..9 observed others):
+    round 2's fp32 matrix-core kernel (CAGYM_GA3C=mfma32) and round 1's vector kernel (=valu) evaluate the same fmaf chain with
+    different gate non-linearities (probabilities to 1e-5); the default split-f16 kernel (three 16-bit matrix instructions per product, csrc/cagym_ga3c16.h) is
+    held to fp32-CLASS accuracy: its distance to the fp64 restatement (oracle/ga3c_ref.py) may not exceed 2 x the fp32 kernels'
+    own distance + 1e-6, it agrees with them to 1e-5, and every kernel picks the same action wherever the margin is clear."""
     import torch
     B = importlib.import_module("gym-exploration-2d_amd.batched_env").BatchedCollisionAvoidanceEnv
     GA3C = importlib.import_module("gym-exploration-2d_amd.ga3c").GA3CCADRLPolicy
@@ -127,23 +139,30 @@ def test_matrix_core_and_vector_forward_kernels_agree():
     env.set_scenarios(scen.random_worlds_fast(N, M, seed=8), np.full((N, M), scen.POLICY_GA3C, dtype=np.int32), scen.DYN_UNICYCLE, n_agents=n_agents)
     env.reset()
     policy = GA3C(env)
-    ext = torch.zeros((N, M, 2), dtype=torch.float32, device=env.device)
+    W = np.load(WEIGHTS)
+    worst = {"valu": 0.0, "mfma32": 0.0, "h16": 0.0, "h16-valu": 0.0}
     for t in range(12):
-        policy.states()
-        os.environ["CAGYM_GA3C"] = "valu"
-        try:
-            act_v, p_v = policy.forward(want_probs=True)
-        finally:
-            del os.environ["CAGYM_GA3C"]
-        act_m, p_m = policy.forward(want_probs=True)
+        st = policy.states()
+        act_v, p_v = _forward_with(policy, "valu")
+        act_m, p_m = _forward_with(policy, "mfma32")
+        act_h, p_h = _forward_with(policy, None)
         torch.cuda.synchronize()
-        assert act_m.numel() == int(n_agents.sum()) or t > 0
-        pv, pm = p_v.double().cpu().numpy(), p_m.double().cpu().numpy()
-        assert np.isfinite(pm).all() and np.abs(pm.sum(1) - 1.0).max() < 1e-5
+        assert act_h.numel() == int(n_agents.sum()) or t > 0
+        pv, pm, ph = (p.double().cpu().numpy() for p in (p_v, p_m, p_h))
+        rows = st.reshape(-1, 76)[policy.agent_index().long()].double().cpu().numpy()
+        p64 = ga3c_ref.forward(W, rows[:, 1:])
+        for p in (pm, ph):
+            assert np.isfinite(p).all() and np.abs(p.sum(1) - 1.0).max() < 1e-5
         assert np.abs(pv - pm).max() <= 1e-5, t
-        top2 = np.sort(pv, axis=1)[:, -2:]
+        assert np.abs(pv - ph).max() <= 1e-5, t
+        ev, em, eh = np.abs(pv - p64).max(), np.abs(pm - p64).max(), np.abs(ph - p64).max()
+        assert eh <= 2 * max(ev, em) + 1e-6, (t, ev, em, eh)
+        worst = {"valu": max(worst["valu"], ev), "mfma32": max(worst["mfma32"], em), "h16": max(worst["h16"], eh),
+                 "h16-valu": max(worst["h16-valu"], np.abs(pv - ph).max())}
+        top2 = np.sort(p64, axis=1)[:, -2:]
         clear = (top2[:, 1] - top2[:, 0]) > 1e-4
-        assert (act_v.cpu().numpy() == act_m.cpu().numpy())[clear].all()
+        for a in (act_v, act_m, act_h):
+            assert (a.cpu().numpy() == p64.argmax(1))[clear].all()
         # the fused entry (device-side selection, states of the selected agents only) writes the same actions as the three-call path
         ext3 = torch.full((N, M, 2), 7.0, dtype=torch.float32, device=env.device)
         extf = torch.full((N, M, 2), 7.0, dtype=torch.float32, device=env.device)
@@ -152,6 +171,55 @@ def test_matrix_core_and_vector_forward_kernels_agree():
         torch.cuda.synchronize()
         assert torch.equal(ext3, extf), t
         env.step(extf)
+    print("max |p - p_fp64|: vector fp32 %.2e, fp32 matrix cores %.2e, split-f16 matrix cores %.2e; split-f16 vs fp32 %.2e"
+          % (worst["valu"], worst["mfma32"], worst["h16"], worst["h16-valu"]))
+    env.close()
+
+
+@pytest.mark.gpu
+def test_split_f16_forward_on_wide_ranges_and_blob_reload():
+    """The split-f16 kernel away from the network's usual operating point: state rows with large distances / speeds (activations far
+    above 1, where an UNSCALED f16 low half would still be fine, and tiny ones, where it would go subnormal), every sequence length
+    0..10 inside one 32-agent tile, a batch that is not a multiple of 32.  Then the blob is rewritten IN PLACE: the handle's packed
+    copy is stale until cagym_ga3c_load_weights, and follows afterwards."""
+    import torch
+    B = importlib.import_module("gym-exploration-2d_amd.batched_env").BatchedCollisionAvoidanceEnv
+    GA3C = importlib.import_module("gym-exploration-2d_amd.ga3c").GA3CCADRLPolicy
+    env = B(8, 20, game_over_mode="all")
+    env.set_scenarios(scen.random_worlds_fast(8, 20, seed=1), np.full((8, 20), scen.POLICY_GA3C, dtype=np.int32), scen.DYN_UNICYCLE)
+    env.reset()
+    policy = GA3C(env)
+    W = np.load(WEIGHTS)
+    rng = np.random.default_rng(12)
+    Bn = 32 * 9 + 5
+    rows = np.zeros((Bn, 76), dtype=np.float32)
+    nseq = rng.integers(0, 11, Bn)
+    nseq[:11] = np.arange(11)
+    scale = np.where(rng.random(Bn) < 0.3, 1e-3, np.where(rng.random(Bn) < 0.5, 1.0, 30.0))
+    rows[:, 1] = nseq
+    rows[:, 2:6] = (rng.normal(size=(Bn, 4)) * [4, 1.5, .3, .2] + [6, 0, 1, .5]) * scale[:, None]
+    for g in range(Bn):
+        rows[g, 6:6 + 7 * nseq[g]] = rng.normal(size=7 * nseq[g]) * 3 * scale[g]
+    p64 = ga3c_ref.forward(W, rows[:, 1:].astype(np.float64))
+    dev_rows = torch.from_numpy(rows).to(env.device)
+    idx = torch.arange(Bn, device=env.device, dtype=torch.int32)
+    act_h, p_h = _forward_with(policy, None, state_rows=dev_rows, agent_idx=idx)
+    act_m, p_m = _forward_with(policy, "mfma32", state_rows=dev_rows, agent_idx=idx)
+    torch.cuda.synchronize()
+    ph, pm = p_h.double().cpu().numpy(), p_m.double().cpu().numpy()
+    eh, em = np.abs(ph - p64).max(), np.abs(pm - p64).max()
+    print("wide ranges: max |p - p_fp64| split-f16 %.2e, fp32 matrix cores %.2e" % (eh, em))
+    assert np.isfinite(ph).all() and eh <= 2 * em + 1e-6 and np.abs(ph - pm).max() <= 2e-5
+    top2 = np.sort(p64, axis=1)[:, -2:]
+    clear = (top2[:, 1] - top2[:, 0]) > 1e-4
+    assert (act_h.cpu().numpy() == p64.argmax(1))[clear].all()
+    # in-place rewrite of the blob: stale until told
+    policy.blob[170507 - 11:] += torch.tensor([0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 50.], device=env.device)  # logits bias: action 10 wins
+    act_stale, _ = _forward_with(policy, None, state_rows=dev_rows, agent_idx=idx)
+    policy.load_weights()
+    act_new, _ = _forward_with(policy, None, state_rows=dev_rows, agent_idx=idx)
+    torch.cuda.synchronize()
+    assert torch.equal(act_stale, act_h) and (act_new.cpu().numpy() == 10).all()
     env.close()
 
 
