@@ -799,8 +799,17 @@ int cagym_ga3c_act(void* env, const float* weights, int max_observed, void* work
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int which = ga3c_kernel_choice();
     if (which == GA_KERNEL_BAD) return fail(e, CAGYM_E_INVALID, "CAGYM_GA3C: unknown forward kernel (h16, mfma32 or valu)");
-    if (which == GA_KERNEL_H16)
+    if (which == GA_KERNEL_H16) {  // one launch: list, state rows and network per workgroup of 32 worlds (cagym_ga3c16.h); `work` is not used
         if (int rc = ga3c_pack(e, weights, st, false)) return rc;
+        const unsigned grid = (unsigned)((e->cfg.n_worlds + 31) / 32);
+        if (e->cfg.max_agents <= 16)
+            hipLaunchKernelGGL(k_ga3c_act_h16<16>, dim3(grid), dim3(512), 0, st, e->D, e->ga3c_packed, max_observed, ext_actions);
+        else
+            hipLaunchKernelGGL(k_ga3c_act_h16<32>, dim3(grid), dim3(512), 0, st, e->D, e->ga3c_packed, max_observed, ext_actions);
+        HIPCHK(e, hipGetLastError());
+        return CAGYM_OK;
+    }
+    // CAGYM_GA3C=mfma32 / valu (A/B): the three-launch chain of rounds 2 - 3
     const size_t total = (size_t)e->cfg.n_worlds * e->cfg.max_agents;
     int32_t* idx = reinterpret_cast<int32_t*>(reinterpret_cast<unsigned char*>(work) + 256);
     float* state = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(work) + 256 + a16(total * sizeof(int32_t)));
@@ -819,12 +828,8 @@ int cagym_ga3c_act(void* env, const float* weights, int max_observed, void* work
     // the list length stays on the device: both kernels are launched for the worst case and leave beyond it
     launch_ga3c_state(e, max_observed, idx, (long long)total, ctr, state, st);
     if (int rc = launched("k_ga3c_state")) return rc;
-    if (which == GA_KERNEL_H16)
-        hipLaunchKernelGGL(k_ga3c_forward_h16, dim3((unsigned)((total + 31) / 32)), dim3(512), 0, st, e->ga3c_packed, state, idx, 0, e->ga3c_ctr + 2,
-                           e->D.pref, ext_actions, (int32_t*)nullptr, (float*)nullptr, ctr);
-    else  // the vector kernel has no device-side count: the fp32 matrix-core kernel stands in for it here
-        hipLaunchKernelGGL(k_ga3c_forward_mfma, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, st, weights, state, idx, 0, e->ga3c_ctr + 2, e->D.pref,
-                           ext_actions, (int32_t*)nullptr, (float*)nullptr, ctr);
+    hipLaunchKernelGGL(k_ga3c_forward_mfma, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, st, weights, state, idx, 0, e->ga3c_ctr + 2, e->D.pref,
+                       ext_actions, (int32_t*)nullptr, (float*)nullptr, ctr);
     if (int rc = launched("k_ga3c_forward")) return rc;
     return CAGYM_OK;
 }
@@ -867,8 +872,8 @@ int cagym_ga3c_forward(void* env, const float* weights, const float* state, cons
     if (which == GA_KERNEL_BAD) return fail(e, CAGYM_E_INVALID, "CAGYM_GA3C: unknown forward kernel (h16, mfma32 or valu)");
     if (which == GA_KERNEL_H16) {
         if (int rc = ga3c_pack(e, weights, st, false)) return rc;
-        hipLaunchKernelGGL(k_ga3c_forward_h16, dim3((unsigned)((B + 31) / 32)), dim3(512), 0, st, e->ga3c_packed, state, agent_idx, B,
-                           (const int32_t*)nullptr, e->D.pref, ext_actions, action_index, probs, (uint32_t*)nullptr);
+        hipLaunchKernelGGL(k_ga3c_forward_h16, dim3((unsigned)((B + 31) / 32)), dim3(512), 0, st, e->ga3c_packed, state, agent_idx, B, e->D.pref,
+                           ext_actions, action_index, probs);
     } else if (which == GA_KERNEL_MFMA32)
         hipLaunchKernelGGL(k_ga3c_forward_mfma, dim3((unsigned)((B + 31) / 32)), dim3(256), 0, st, weights, state, agent_idx, B,
                            (const int32_t*)nullptr, e->D.pref, ext_actions, action_index, probs, (uint32_t*)nullptr);

@@ -19,7 +19,8 @@ print("library", TAG)
 scen = importlib.import_module("gym-exploration-2d_amd.scenarios")
 B = importlib.import_module("gym-exploration-2d_amd.batched_env").BatchedCollisionAvoidanceEnv
 GA3C = importlib.import_module("gym-exploration-2d_amd.ga3c").GA3CCADRLPolicy
-NAMES = ["prologue (state rows, LSTM weights)", "LSTM steps", "layer1 68 -> 256", "layer2 256 -> 256", "layer3 256 -> 256", "logits, softmax, action"]
+NAMES = ["prologue (state rows -> operand fragments, LSTM weights)", "LSTM steps", "layer1 68 -> 256", "layer2 256 -> 256", "layer3 256 -> 256", "logits, softmax, action",
+         "cagym_ga3c_act only: agent list + state rows in LDS (before the prologue)"]
 for name, N, M in (("agent0_8192", 8192, 10), ("all_agents_81920", 8192, 10)):
     pol = np.full((N, M), scen.POLICY_GA3C if "all" in name else scen.POLICY_RVO, dtype=np.int32)
     pol[:, 0] = scen.POLICY_GA3C
@@ -40,7 +41,7 @@ for name, N, M in (("agent0_8192", 8192, 10), ("all_agents_81920", 8192, 10)):
     torch.cuda.synchronize()
     env.L.cagym_debug_stamps(out, 0)
     wg = max(1, out[15])
-    tot = sum(out[:6])
+    tot = sum(out[:7])
     print("%s: %d workgroups per launch, s_memtime ticks (shader clock, ~2.2 GHz) per workgroup: total %.1f" % (name, wg // R, tot / wg))
     for i, n in enumerate(NAMES):
         print("  %-40s %9.1f  %5.1f %%" % (n, out[i] / wg, 100.0 * out[i] / max(1, tot)))
