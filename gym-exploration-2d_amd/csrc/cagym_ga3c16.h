@@ -227,6 +227,33 @@ __device__ __forceinline__ void ga16_dense256(Ga16Stage& X, Ga16Stage& Y, const 
 #define GA16_LDS_ACT (GA16_LDS_ZERO + 1024)          /* 16 K-steps of layer activations */
 #define GA16_LDS_BYTES (GA16_LDS_ACT + 16 * GA16_KSTEP)
 
+// What a wave keeps in registers from the start of a tile: its rows of the LSTM kernel and of layer1's (which follows the sequence
+// without a pause), their biases, one logit bias.  Requested by the caller BEFORE it builds / fetches the tile's state rows, so
+// that the (cold: the env kernel has streamed through L2 since the last call) loads travel while that happens.
+struct Ga16Pre {
+    ga_h8 Ah[5], Al[5], A1h[5], A1l[5];
+    ga_f32x16 bl, b1;
+    float lo_bias;
+};
+__device__ __forceinline__ void ga16_preload(const unsigned char* __restrict__ P, Ga16Pre& W) {
+    const int n = threadIdx.x, lane = n & 63, wave = __builtin_amdgcn_readfirstlane(n >> 6), half = lane >> 5;
+    const uint4* PAL = reinterpret_cast<const uint4*>(P + GA16_OFF_LSTM) + wave * (5 * 128) + lane;
+    const uint4* PA1 = reinterpret_cast<const uint4*>(P + GA16_OFF_L1) + wave * (5 * 128) + lane;
+#pragma unroll
+    for (int s = 0; s < 5; s++) {
+        W.Ah[s] = ga16_ldg(PAL + s * 128);
+        W.Al[s] = ga16_ldg(PAL + s * 128 + 64);
+    }
+#pragma unroll
+    for (int s = 0; s < 5; s++) {
+        W.A1h[s] = ga16_ldg(PA1 + s * 128);
+        W.A1l[s] = ga16_ldg(PA1 + s * 128 + 64);
+    }
+    W.lo_bias = reinterpret_cast<const float*>(P + GA16_OFF_BIAS)[4 * 256 + (n - (n / 11) * 11)];  // thread n sums logit n % 11 of agent n / 11
+    W.bl = ga16_bias(P, 0, wave, half);
+    W.b1 = ga16_bias(P, 1, wave, half);
+}
+
 // where a tile's 32 state rows ([id, n_others, dist_to_goal, heading_ego, pref_speed, radius, 10 x 7 features], cagym_ga3c_state) come from
 struct Ga16RowsGlobal {  // cagym_ga3c_forward: a [*, 76] table in HBM, rows by agent index (or by place in the list)
     const float* state;
@@ -247,7 +274,7 @@ struct Ga16RowsLds {  // cagym_ga3c_act: the rows the workgroup has just built i
 // preferred speed (requested by the caller ahead of time: the action write is the very last thing); action_index / probs_row: this
 // thread's own output slots or null.  lds: GA16_LDS_BYTES; ends with every lane past the last barrier that reads it.
 template <class Rows>
-__device__ __forceinline__ void ga16_forward_tile(const unsigned char* __restrict__ P, unsigned char* lds, int* nseq, const Rows& rows, bool act_valid,
+__device__ __forceinline__ void ga16_forward_tile(const unsigned char* __restrict__ P, const Ga16Pre& W, unsigned char* lds, int* nseq, const Rows& rows, bool act_valid,
                                                   int act_a, double act_pref, float* ext_actions, int32_t* action_index, float* probs_row) {
     constexpr int AG = 32;
     unsigned char* hbuf = lds + GA16_LDS_H;
@@ -297,25 +324,10 @@ __device__ __forceinline__ void ga16_forward_tile(const unsigned char* __restric
     }
     for (int e = n; e < (2 * 4 * GA16_KSTEP) / 16; e += 512) reinterpret_cast<uint4*>(hbuf)[e] = make_uint4(0, 0, 0, 0);  // h = 0
     if (n < 64) reinterpret_cast<uint4*>(zero)[n] = make_uint4(0, 0, 0, 0);
-    // this wave's rows of the LSTM kernel (and of layer1's, which follows without a pause) stay in registers: 2 x 40 VGPRs
-    const uint4* PAL = reinterpret_cast<const uint4*>(P + GA16_OFF_LSTM) + wave * (5 * 128) + lane;
-    const uint4* PA1 = reinterpret_cast<const uint4*>(P + GA16_OFF_L1) + wave * (5 * 128) + lane;
-    ga_h8 Ah[5], Al[5], A1h[5], A1l[5];
-#pragma unroll
-    for (int s = 0; s < 5; s++) {
-        Ah[s] = ga16_ldg(PAL + s * 128);
-        Al[s] = ga16_ldg(PAL + s * 128 + 64);
-    }
-#pragma unroll
-    for (int s = 0; s < 5; s++) {
-        A1h[s] = ga16_ldg(PA1 + s * 128);
-        A1l[s] = ga16_ldg(PA1 + s * 128 + 64);
-    }
-    // logit (agent lo_g, action lo_o) is summed by thread n < 352 at the very end: its bias is requested here
-    const int lo_g = n / 11, lo_o = n - lo_g * 11;
-    const float lo_bias = reinterpret_cast<const float*>(P + GA16_OFF_BIAS)[4 * 256 + lo_o];
-    const ga_f32x16 bl = ga16_bias(P, 0, wave, half);
-    const ga_f32x16 b1 = ga16_bias(P, 1, wave, half);
+    const ga_h8 (&Ah)[5] = W.Ah, (&Al)[5] = W.Al, (&A1h)[5] = W.A1h, (&A1l)[5] = W.A1l;
+    const ga_f32x16 bl = W.bl, b1 = W.b1;
+    const int lo_g = n / 11, lo_o = n - lo_g * 11;  // logit (agent lo_g, action lo_o) is summed by thread n < 352 at the very end
+    const float lo_bias = W.lo_bias;
     const ga_f32x16 zero16 = ga_splat(0.f);
     __syncthreads();
     GASTAMP(0);
@@ -492,8 +504,10 @@ __global__ void __launch_bounds__(512) k_ga3c_forward_h16(const unsigned char* _
         act_a = agent_idx[tile + n];
         act_pref = pref[act_a];
     }
+    Ga16Pre W;
+    ga16_preload(P, W);
     const Ga16RowsGlobal rows{state, agent_idx, tile, B, false};
-    ga16_forward_tile(P, lds, nseq, rows, act_valid, act_a, act_pref, ext_actions, action_index && act_valid ? action_index + tile + n : nullptr,
+    ga16_forward_tile(P, W, lds, nseq, rows, act_valid, act_a, act_pref, ext_actions, action_index && act_valid ? action_index + tile + n : nullptr,
                       probs && act_valid ? probs + (size_t)(tile + n) * 11 : nullptr);
 }
 
@@ -517,14 +531,18 @@ __global__ void __launch_bounds__(512) k_ga3c_act_h16(CagymDev D, const unsigned
     const int nslots = (int)((total - first) < (size_t)(32 * D.M) ? (total - first) : (size_t)(32 * D.M));  // <= 1024: two passes of 512
     unsigned long long m[2];
     bool take[2];
+    uint32_t st[2];
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) st[pass] = pass * 512 + n < nslots ? D.status[first + pass * 512 + n] : 0u;
+    // the first tile's weights travel while the agents are listed and their state rows built (requested BEHIND the status words:
+    // vector loads return in order)
+    Ga16Pre W;
+#ifndef GA16_NO_HOIST  /* A/B only */
+    ga16_preload(P, W);
+#endif
 #pragma unroll
     for (int pass = 0; pass < 2; pass++) {
-        const int sidx = pass * 512 + n;
-        take[pass] = false;
-        if (sidx < nslots) {
-            const uint32_t st = D.status[first + sidx];
-            take[pass] = (st & CAGYM_FLAG_ACTIVE) && ST_POLICY(st) == CAGYM_POL_GA3C;
-        }
+        take[pass] = (st[pass] & CAGYM_FLAG_ACTIVE) && ST_POLICY(st[pass]) == CAGYM_POL_GA3C;
         m[pass] = __ballot(take[pass]);
         if (lane == 0) wcnt[pass][wave] = __popcll(m[pass]);
     }
@@ -565,9 +583,13 @@ __global__ void __launch_bounds__(512) k_ga3c_act_h16(CagymDev D, const unsigned
             __syncthreads();  // rows complete; the next pass may overwrite the keys
         }
         GASTAMP(6);
+#ifdef GA16_NO_HOIST
+        if (tile == 0) ga16_preload(P, W);
+#endif
         const Ga16RowsLds r{rows, nvalid};
-        ga16_forward_tile(P, lds, nseq, r, act_valid, act_a, act_pref, ext_actions, (int32_t*)nullptr, (float*)nullptr);
+        ga16_forward_tile(P, W, lds, nseq, r, act_valid, act_a, act_pref, ext_actions, (int32_t*)nullptr, (float*)nullptr);
         __syncthreads();  // the next tile's rows overwrite the activation buffer
+        if (tile + 32 < cnt) ga16_preload(P, W);
     }
 }
 
