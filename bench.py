@@ -67,7 +67,7 @@ def parse_args(argv=None):
     ap.add_argument("--repeats", type=int, default=0, help="timed blocks (0 = at least 5, more while the blocks are short)")
     ap.add_argument("--per-step-launch", action="store_true", help="one cagym_step_autoreset launch per env step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--halves", type=int, default=1, help="cfg4: split the rank's worlds into this many independent groups, each with its own handle and HIP stream, so that one group's GA3C forward (matrix cores) overlaps another group's env step (vector units); 1 = one group (measured: 0.302 ms with 1, 0.383 with 2, 0.500 with 4 - cagym_ga3c_act costs 78 us for half the worlds, 84 us for all: not kept as default)")
+    ap.add_argument("--halves", type=int, default=1, help="cfg4: split the rank's worlds into this many independent groups, each with its own handle and HIP stream, so that one group's GA3C forward (matrix cores) overlaps another group's env step (vector units); 1 = one group (measured, round 4: 0.147 ms with 1, 0.190 with 2 - the forward is one latency-bound workgroup per CU whatever the number of worlds; round 3: 0.302 / 0.383 / 0.500 with 1 / 2 / 4: not kept as default)")
     ap.add_argument("--cfg4-step", default="fused", choices=["fused", "split", "overlap"],
                     help="cfg4: fused = cagym_ga3c_act, then cagym_step_autoreset (default; round 4: time-shared LDS, four workgroups per CU); "
                          "split = cagym_step_begin, cagym_ga3c_act, cagym_step_finish on one stream; overlap = cagym_step_begin on a side stream BESIDE "
@@ -272,7 +272,7 @@ def main():
             kernel_name = env.kernel_name(rollout=False, auto_reset=True)
 
         # --halves H > 1: worlds are independent, so the rank's worlds are dealt to H handles, each on its own HIP stream: group A's
-        # GA3C forward (fp32 MFMA) runs beside group B's env kernel (VALU / LDS, two workgroups per CU) instead of after it
+        # GA3C forward (matrix cores) runs beside group B's env kernel (VALU / LDS, two workgroups per CU) instead of after it
         groups = [(env, ga3c, ext, None)]
         if args.halves > 1:
             H = args.halves
@@ -347,7 +347,11 @@ def main():
             t_nn = loop(lambda: ga3c.act(ext))
             t_env = loop(lambda: env.step(ext, auto_reset=True))
             n0 = env.N  # = N, or one group's worlds with --halves
-            r = {"ga3c_evals_per_s": n0 / t_nn, "ga3c_ms_per_step": 1e3 * t_nn, "ga3c_tflops_fp32": n0 * 0.67e6 / t_nn / 1e12,
+            r = {"ga3c_evals_per_s": n0 / t_nn, "ga3c_ms_per_step": 1e3 * t_nn, "ga3c_network_tflops": n0 * 0.67e6 / t_nn / 1e12,
+                 "ga3c_note": "cagym_ga3c_act = ONE launch (agent list, state rows, LSTM-64 + 3 x FC-256 + logits per workgroup of 32 worlds); "
+                              "ga3c_network_tflops counts the network's 0.67 MFLOP per evaluation once - the kernel issues three "
+                              "v_mfma_f32_32x32x16_f16 per product (fp32 operands split into two f16 halves, fp32 accumulation: "
+                              "csrc/cagym_ga3c16.h; max |p - p_fp64| 2.2e-6 against 1.7e-6 for the exact-fp32 matrix-core kernel, tests/test_ga3c.py)",
                  "fused_env_kernel_ms_per_step": 1e3 * t_env, "kernels_timed_alone_on_worlds": n0,
                  "fused_env_kernel_hbm_frac": balg * n0 * M / t_env / (HBM_PEAK_GBS * 1e9)}
             if split:

@@ -203,10 +203,12 @@ int cagym_ga3c_forward(void* env, const float* weights, const float* state, cons
                        float* ext_actions, int32_t* action_index, float* probs, void* stream);
 
 /* GA3CCADRLPolicy.find_next_action (policies/GA3CCADRLPolicy.py:34-43) for EVERY active agent whose policy id is
- * CAGYM_POL_GA3C, in one call and without a host round trip: their indices are compacted on the device, their state
- * vectors built (only theirs, as the reference does per agent), the network evaluated and (pref_speed * a0, a1) written to
- * their rows of ext_actions [N*M, 2] f32; other rows are untouched.  work: caller-owned DEVICE scratch of
- * cagym_ga3c_act_workspace_bytes(env) bytes (its contents are overwritten; layout private). */
+ * CAGYM_POL_GA3C, in one call and without a host round trip: the agents are listed on the device, their state vectors built
+ * (only theirs, as the reference does per agent), the network evaluated and (pref_speed * a0, a1) written to their rows of
+ * ext_actions [N*M, 2] f32; other rows are untouched.  ONE kernel launch (round 4: a workgroup per 32 worlds lists its agents,
+ * keeps their state vectors in LDS and runs the network on them); it replays from a captured HIP graph.  work: caller-owned
+ * DEVICE scratch of cagym_ga3c_act_workspace_bytes(env) bytes - used (overwritten; layout private) only by the A/B kernels
+ * CAGYM_GA3C=mfma32 / valu, which run the three-launch chain of rounds 2 - 3; one call per handle in flight. */
 size_t cagym_ga3c_act_workspace_bytes(void* env);
 int cagym_ga3c_act(void* env, const float* weights, int max_observed, void* work, float* ext_actions, void* stream);
 
