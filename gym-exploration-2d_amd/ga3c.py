@@ -59,6 +59,8 @@ class GA3CCADRLPolicy(object):
         assert self.blob.numel() == 170507
         self._idx = None
         self._idx_episode = None
+        # the handle caches the packed blob by ADDRESS: a policy built after another one was freed may get the same address back
+        self.load_weights()
 
     def load_weights(self):
         """Tell the handle that `self.blob` was rewritten in place (it caches the blob as matrix-core operand fragments by address)."""
